@@ -1,0 +1,150 @@
+/*
+ * obnsl_engine.h -- C ABI of the MI355X local-score engine (libobnsl_engine.so).
+ *
+ * The reference has no C ABI: its boundary is a pybind11 module over C++ free
+ * functions and structs.  Each entry point below names the reference interface
+ * it replaces (file:line relative to the reference checkout).  The pybind11
+ * module openbnsllib (openbnsl_amd/host/) is a thin shim over these calls and
+ * keeps the reference's Python names, argument meaning and exception types.
+ *
+ * Conventions
+ *  - every function returns an obnsl_status; nothing throws across the ABI;
+ *    obnsl_last_error() gives the message of the calling thread's last failure;
+ *  - the data matrix is uint8 state codes, column-major: code of variable v in
+ *    row i is codes[v * col_stride + i]  (reference: data_column_major,
+ *    include/base/dataframe_wrapper.h:42-43);
+ *  - a variable subset is an ascending list of variable ids; its joint table is
+ *    dense, keyed as the reference keys it: the LAST variable has radix weight 1
+ *    (reference: include/base/contingency_table.h:43-49,77-85);
+ *  - size-k subsets are numbered by colex rank, rank(S) = sum_j C(v_j, j) for
+ *    v_1 < ... < v_k, which is the order in which the reference visits them
+ *    (Gosper order, src/structure_learning/exhaustive_search.cpp:51-52,129);
+ *  - all compute runs on the GPU; there is no CPU fallback.  Without a usable
+ *    HIP device every compute call fails with OBNSL_ERR_NO_DEVICE.
+ */
+#ifndef OBNSL_ENGINE_H
+#define OBNSL_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  OBNSL_OK = 0,
+  OBNSL_ERR_INVALID_ARGUMENT = 1, /* reference: std::invalid_argument -> ValueError */
+  OBNSL_ERR_OUT_OF_RANGE = 2,     /* reference: std::out_of_range    -> IndexError */
+  OBNSL_ERR_RUNTIME = 3,          /* reference: std::runtime_error   -> RuntimeError */
+  OBNSL_ERR_NO_DEVICE = 4,        /* no HIP device / HIP runtime failure at init */
+  OBNSL_ERR_UNSUPPORTED = 5       /* "Unsupported score type." (local_score.h:42-44) */
+} obnsl_status;
+
+/* reference: std::variant<BDeu,K2,BIC,AIC>, include/score/score_type.h:39.
+ * BDeu is what the reference implements; BIC is this engine's addition (the
+ * reference throws for it); K2 and AIC are rejected as the reference rejects
+ * them. */
+typedef enum {
+  OBNSL_SCORE_BDEU = 0,
+  OBNSL_SCORE_K2 = 1,
+  OBNSL_SCORE_BIC = 2,
+  OBNSL_SCORE_AIC = 3
+} obnsl_score_kind;
+
+#define OBNSL_MAX_SUBSET 8 /* largest subset size (max_parents + 1) the engine scores */
+
+typedef struct obnsl_data obnsl_data; /* device-resident data set (opaque) */
+
+const char* obnsl_last_error(void);
+int obnsl_abi_version(void);
+
+/* Number of visible HIP devices (0 when there is none; never fails for that). */
+obnsl_status obnsl_device_count(int* count);
+
+/* Replaces the storage half of DataframeWrapper
+ * (include/base/dataframe_wrapper.h:33-45): uploads the coded data matrix and
+ * the observed cardinalities (num_of_values) to `device` and builds the
+ * per-(variable,state) row bitmaps the counting kernels read.
+ * codes_on_device != 0: `codes` is a device pointer on `device` (no host copy). */
+obnsl_status obnsl_data_create(const uint8_t* codes, uint64_t num_rows, uint64_t col_stride,
+                               uint32_t num_vars, const uint32_t* cardinalities, int device,
+                               int codes_on_device, obnsl_data** out);
+obnsl_status obnsl_data_destroy(obnsl_data* d);
+
+/* Work is queued on this HIP stream (a hipStream_t; NULL = the null stream).
+ * Calls that return results to host memory synchronise it before returning. */
+obnsl_status obnsl_data_set_stream(obnsl_data* d, void* hip_stream);
+
+/* Rebuilds the row bitmaps from the resident uint8 matrix (one pass over the
+ * data; obnsl_data_create already did it once).  Asynchronous on the stream. */
+obnsl_status obnsl_data_pack(obnsl_data* d);
+
+/* Replaces ContingencyTable<true>::ContingencyTable(var_ids, df)
+ * (include/base/contingency_table.h:34-56): dense joint counts of the subset,
+ * prod(card) cells written to counts_out (host).  Unsorted var_ids ->
+ * OBNSL_ERR_INVALID_ARGUMENT "var_ids must be sorted" (:37-38). */
+obnsl_status obnsl_count(obnsl_data* d, const uint32_t* var_ids, uint32_t k,
+                         uint64_t* counts_out, uint64_t counts_capacity);
+
+/* Replaces calculate_local_score<double,true>(child, parents, ct, score)
+ * (include/score/local_score.h:22-62) for a table already counted: `counts`
+ * (host, dense, keyed as above) over variables with cardinalities cards[0..k),
+ * child = position child_idx in that list.  The fp64 evaluation runs on
+ * `device`.  K2/AIC -> OBNSL_ERR_UNSUPPORTED. */
+obnsl_status obnsl_local_score(int device, const uint64_t* counts, const uint32_t* cards,
+                               uint32_t k, uint32_t child_idx, obnsl_score_kind kind,
+                               double ess, double* score_out);
+
+/* Replaces the scoring phase of exhaustive_search
+ * (src/structure_learning/exhaustive_search.cpp:47-73) for one subset size:
+ * for every size-k subset in colex-rank order, one joint table and one score
+ * per member taken as the child (members ascending):
+ *   scores_out[rank * k + i] = score(v_i | S \ {v_i}).
+ * shard/num_shards split the subsets over GPUs: this call fills only the
+ * entries of its shard (the partition is by cost, deterministic in
+ * (k, num_shards)) and leaves the others untouched; (0, 1) = everything.
+ * out_on_device != 0: scores_out is a device pointer and the call is
+ * asynchronous on the data set's stream. */
+obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, uint32_t k,
+                             uint32_t shard, uint32_t num_shards, double* scores_out,
+                             int out_on_device);
+
+/* Number of size-k subsets, C(num_vars, k), and of scores, k * C(num_vars, k). */
+obnsl_status obnsl_num_subsets(const obnsl_data* d, uint32_t k, uint64_t* num_subsets);
+
+/* Explicit-list form of the same pair of calls (what a caller such as
+ * simulated_annealing.cpp:77-81 issues one at a time): subsets[m][k] ascending
+ * ids; scores_out[m][k] on the host. */
+obnsl_status obnsl_score_subsets(obnsl_data* d, obnsl_score_kind kind, double ess,
+                                 const uint32_t* subsets, uint32_t k, uint64_t m,
+                                 double* scores_out);
+
+/* Per-node best parent set over all parent sets of size <= max_parents, from
+ * device score tables produced by obnsl_score_all (d_scores[k-1] = table of
+ * subset size k, k = 1..max_parents+1, device pointers).  Entries still equal to
+ * the fill value -inf (other shards) are ignored.  Outputs (host):
+ *   best_score[v]; best_size[v] = number of parents; best_rank[v] = colex rank
+ *   of the parent set among subsets of its size.  Ties: fewer parents, then
+ *   lower rank.  This is the per-GPU partial result that ranks all-gather. */
+obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
+                                uint32_t max_parents, double* best_score,
+                                uint32_t* best_size, uint64_t* best_rank);
+
+/* colex rank <-> subset helpers (host, no GPU). */
+uint64_t obnsl_binomial(uint32_t n, uint32_t k);
+obnsl_status obnsl_unrank(uint64_t rank, uint32_t k, uint32_t* var_ids_out);
+uint64_t obnsl_rank(const uint32_t* var_ids, uint32_t k);
+
+/* Device time spent in the counting kernel (the bit-GEMM) of subset size k by
+ * the obnsl_score_all calls on this data set since the last reset, measured
+ * with HIP events on the data set's stream: total milliseconds and number of
+ * launches.  Waits for the last call's launches if they are still running.
+ * reset != 0 clears the totals of every subset size after reading. */
+obnsl_status obnsl_kernel_time(obnsl_data* d, uint32_t k, double* total_ms, uint32_t* launches,
+                               int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBNSL_ENGINE_H */

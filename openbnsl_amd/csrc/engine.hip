@@ -1,0 +1,1137 @@
+// engine.hip -- MI355X (gfx950) local-score engine behind include/obnsl_engine.h.
+//
+// What the reference does per candidate (child, parent set): walk all N rows,
+// build a sparse joint histogram of the subset (include/base/contingency_table.h
+// :52-55), then evaluate BDeu from it (include/score/local_score.h:49-60).
+//
+// How this engine does it.  The uint8 data matrix is turned once into row
+// bitmaps: one N-bit plane per (variable, state).  A cell count of a joint
+// table is then popcount(AND of the cell's planes).  All tables of one subset
+// size k are produced by one "bit-GEMM": the k variables of a subset are split
+// into the kc smallest ("column side") and the kr = k - kc largest ("row side");
+// rows of the GEMM are the joint states of every kr-subset, columns the joint
+// states of every kc-subset, the contraction runs over the N rows of the data
+// in 32-row words, and C[row][col] = sum_w popc(A[row][w] & B[col][w]).  Only
+// combinations with max(column vars) < min(row vars) are computed (rows are
+// sorted by their smallest variable, so the valid region of each row tile is a
+// prefix of the column list).  This is integer AND/popcount work on the vector
+// ALU fed from LDS; there is no MFMA formulation worth having (one bit per
+// sample vs one byte per int8 MFMA operand).
+//
+// A workgroup owns a 128x128 tile of C, stages 32-word slabs of A and B through
+// LDS (the A/B rows are formed on the fly by ANDing the subset's planes) and
+// each thread keeps an 8x8 block of counters in registers.  Scores are then
+// evaluated from the dense counts by a second kernel, one wavefront per table,
+// in fp64.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "obnsl_engine.h"
+
+namespace {
+
+constexpr int KMAX = OBNSL_MAX_SUBSET;  // largest subset size
+constexpr int KSIDE = 4;                // largest kr / kc
+constexpr int BM = 128, BN = 128;       // C tile of one workgroup
+constexpr int KCW = 32;                 // 32-bit words of the contraction per LDS slab
+constexpr int LDS_STRIDE = KCW + 4;     // padded slab row (words): conflict-free b128 reads
+constexpr uint64_t BATCH_CELL_CAP = 1ull << 30;  // counters per batch (4 GiB)
+
+thread_local std::string g_err;
+
+obnsl_status fail(obnsl_status st, const std::string& msg) {
+  g_err = msg;
+  return st;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(OBNSL_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// ------------------------------------------------------------------ descriptors
+struct RowDesc {        // one row of A: a joint state of a kr-subset
+  uint32_t plane[KSIDE];  // plane index per row-side variable (unused: ONES plane)
+  uint64_t out_base;      // counter index of (this row, column 0)
+  uint32_t M;             // rows in this row group = counter stride per column
+  uint32_t ncols;         // valid columns: those of column groups below min(row vars)
+};
+struct ColDesc {        // one row of B: a joint state of a kc-subset
+  uint32_t plane[KSIDE];
+};
+struct RowGroupDesc {   // scorer view of one kr-subset
+  uint32_t vars[KSIDE];
+  uint64_t out_off;     // first counter of the group: layout [column][M]
+  uint64_t rank_part;   // sum_j C(u_j, kc + j): row-side part of the colex rank
+  uint64_t tbl_start;   // tables of earlier groups in this batch
+  uint32_t M;
+  uint32_t ncolgroups;  // C(u_1, kc) column groups pair with this row group
+};
+struct ColGroupDesc {   // scorer view of one kc-subset
+  uint32_t vars[KSIDE];
+  uint32_t col_before;  // columns of earlier column groups
+  uint32_t cells;
+};
+struct TableDesc {      // explicit table for the list-form / single-table scorer
+  uint64_t off;
+  uint32_t k;
+  uint32_t cards[KMAX];
+};
+
+// ------------------------------------------------------------------ pack kernel
+// One thread builds one 32-row word of every state plane of one variable.
+// Bit b of word w is row 32*w + b.  Rows >= N contribute zero bits.
+__global__ __launch_bounds__(256) void pack_planes_kernel(
+    const uint8_t* __restrict__ codes, uint64_t N, uint64_t stride, uint32_t n,
+    const uint32_t* __restrict__ card, const uint32_t* __restrict__ plane_base,
+    uint32_t* __restrict__ planes, uint32_t wp, uint32_t ones_plane) {
+  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= wp) return;
+  const uint32_t v = blockIdx.y;
+  const uint64_t row0 = (uint64_t)w * 32;
+  uint32_t valid = 0;
+  if (row0 + 32 <= N) valid = 0xffffffffu;
+  else if (row0 < N) valid = (1u << (uint32_t)(N - row0)) - 1u;
+  if (v == n) {  // the all-valid-rows plane
+    planes[(size_t)ones_plane * wp + w] = valid;
+    return;
+  }
+  const uint4* src = reinterpret_cast<const uint4*>(codes + (size_t)v * stride + row0);
+  const uint4 lo = src[0], hi = src[1];
+  const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  const uint32_t r = card[v], base = plane_base[v];
+  for (uint32_t s = 0; s < r; ++s) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        word |= (uint32_t)(((x[i] >> (8 * b)) & 0xffu) == s) << (4 * i + b);
+    }
+    planes[(size_t)(base + s) * wp + w] = word & valid;
+  }
+}
+
+// ------------------------------------------------------------------ bit-GEMM
+__device__ __forceinline__ uint4 and4(uint4 a, uint4 b) {
+  return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w);
+}
+
+// C[row][col] += sum over this split's words of popc(A[row][w] & B[col][w]).
+// 256 threads; thread (tm, tn) owns rows tm + 16 i and columns tn + 16 j
+// (i, j < 8), which makes every ds_read_b128 of the compute phase
+// bank-conflict free with the 36-word slab stride.
+template <int KR, int KC>
+__global__ __launch_bounds__(256) void bitgemm_kernel(
+    const uint32_t* __restrict__ planes, uint32_t wp, const RowDesc* __restrict__ rows,
+    uint32_t nrows, const ColDesc* __restrict__ cols, uint32_t ncols_total,
+    const uint2* __restrict__ items, uint32_t nitems, uint32_t* __restrict__ counts,
+    uint32_t steps_total, uint32_t steps_per_split, int use_atomics) {
+  __shared__ __attribute__((aligned(16))) uint32_t sA[BM * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t sB[BN * LDS_STRIDE];
+
+  const uint32_t item_id = blockIdx.x % nitems;
+  const uint32_t split = blockIdx.x / nitems;
+  const uint2 it = items[item_id];
+  const uint32_t row0 = it.x * BM, col0 = it.y * BN;
+  const uint32_t tid = threadIdx.x;
+
+  // staging role: 8 threads cover one 32-word slab row with one uint4 each
+  const uint32_t q = tid & 7, rl = tid >> 3;
+  uint32_t aoff[4][KR], boff[4][KC];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const uint32_t r = min(row0 + rl + 32 * p, nrows - 1);
+    const uint32_t c = min(col0 + rl + 32 * p, ncols_total - 1);
+#pragma unroll
+    for (int j = 0; j < KR; ++j) aoff[p][j] = rows[r].plane[j] * wp + q * 4;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) boff[p][j] = cols[c].plane[j] * wp + q * 4;
+  }
+
+  const uint32_t tn = tid & 15, tm = tid >> 4;
+  uint32_t acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0;
+
+  const uint32_t step_lo = split * steps_per_split;
+  const uint32_t step_hi = min(step_lo + steps_per_split, steps_total);
+  for (uint32_t step = step_lo; step < step_hi; ++step) {
+    const uint32_t w0 = step * KCW;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      uint4 va = *reinterpret_cast<const uint4*>(planes + aoff[p][0] + w0);
+#pragma unroll
+      for (int j = 1; j < KR; ++j)
+        va = and4(va, *reinterpret_cast<const uint4*>(planes + aoff[p][j] + w0));
+      uint4 vb = *reinterpret_cast<const uint4*>(planes + boff[p][0] + w0);
+#pragma unroll
+      for (int j = 1; j < KC; ++j)
+        vb = and4(vb, *reinterpret_cast<const uint4*>(planes + boff[p][j] + w0));
+      *reinterpret_cast<uint4*>(&sA[(rl + 32 * p) * LDS_STRIDE + q * 4]) = va;
+      *reinterpret_cast<uint4*>(&sB[(rl + 32 * p) * LDS_STRIDE + q * 4]) = vb;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kq = 0; kq < KCW / 4; ++kq) {
+      uint4 a[8], b[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        a[i] = *reinterpret_cast<const uint4*>(&sA[(tm + 16 * i) * LDS_STRIDE + kq * 4]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        b[j] = *reinterpret_cast<const uint4*>(&sB[(tn + 16 * j) * LDS_STRIDE + kq * 4]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc[i][j] += __popc(a[i].x & b[j].x);
+          acc[i][j] += __popc(a[i].y & b[j].y);
+          acc[i][j] += __popc(a[i].z & b[j].z);
+          acc[i][j] += __popc(a[i].w & b[j].w);
+        }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t r = row0 + tm + 16 * i;
+    if (r >= nrows) continue;
+    const RowDesc rd = rows[r];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t c = col0 + tn + 16 * j;
+      if (c >= rd.ncols) continue;
+      uint32_t* dst = counts + rd.out_base + (uint64_t)c * rd.M;
+      if (use_atomics) atomicAdd(dst, acc[i][j]);
+      else *dst = acc[i][j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ single table
+// Dense counts of one explicit subset: counts[cell] += popc(AND of the cell's
+// planes) over this block's share of the words.  Generic and simple: it serves
+// the one-table calls (ContingencyTable(var_ids, df)), not the batch path.
+__global__ __launch_bounds__(256) void count_single_kernel(
+    const uint32_t* __restrict__ planes, uint32_t wp, uint32_t k, const uint32_t* __restrict__ pbase,
+    const uint32_t* __restrict__ cards, uint32_t cells, uint32_t* __restrict__ counts,
+    uint32_t ones_plane) {
+  __shared__ uint32_t red[4];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t cell = blockIdx.y; cell < cells; cell += gridDim.y) {
+    uint32_t pl[KMAX];
+    uint32_t rem = cell;
+    for (int j = (int)k - 1; j >= 0; --j) {
+      pl[j] = pbase[j] + rem % cards[j];
+      rem /= cards[j];
+    }
+    uint32_t acc = 0;
+    for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < wp; w += gridDim.x * 256) {
+      uint32_t x = planes[(size_t)ones_plane * wp + w];
+      for (uint32_t j = 0; j < k; ++j) x &= planes[(size_t)pl[j] * wp + w];
+      acc += __popc(x);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t tot = red[0] + red[1] + red[2] + red[3];
+      if (tot) atomicAdd(&counts[cell], tot);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ scoring
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// All k local scores of one dense table, by one wavefront (lane = 0..63).
+// BDeu as the reference writes it (include/score/local_score.h:38-61): only
+// non-zero cells and non-zero parent configurations contribute; alpha_ijk =
+// ess / prod(card), alpha_ij = alpha_ijk * r_child.  The sums are taken
+// lane-strided and combined by a fixed butterfly, so results are reproducible
+// run to run (the reference adds the same terms one by one in key order).
+// BIC (not in the reference): sum N_ijk ln N_ijk - sum N_ij ln N_ij
+//                             - 0.5 ln(N) q (r - 1).
+__device__ void score_table(const uint32_t* __restrict__ cnt, uint32_t k, const uint32_t* cards,
+                            int kind, double ess, uint32_t lane, double* out) {
+  uint32_t cells = 1;
+  for (uint32_t i = 0; i < k; ++i) cells *= cards[i];
+  double a_ijk = 0.0, lg_a_ijk = 0.0;
+  if (kind == OBNSL_SCORE_BDEU) {
+    a_ijk = ess / (double)cells;
+    lg_a_ijk = lgamma(a_ijk);
+  }
+  double t1 = 0.0, tot = 0.0;
+  for (uint32_t c = lane; c < cells; c += 64) {
+    const uint32_t nijk = cnt[c];
+    if (nijk == 0) continue;
+    if (kind == OBNSL_SCORE_BDEU) {
+      t1 += lgamma((double)nijk + a_ijk) - lg_a_ijk;
+    } else {
+      t1 += (double)nijk * log((double)nijk);
+      tot += (double)nijk;
+    }
+  }
+  t1 = wave_sum(t1);
+  if (kind != OBNSL_SCORE_BDEU) tot = wave_sum(tot);
+  uint32_t w = 1;  // radix weight of variable i
+  for (int i = (int)k - 1; i >= 0; --i) {
+    const uint32_t r = cards[i];
+    const uint32_t q = cells / r;
+    double a_ij = 0.0, lg_a_ij = 0.0;
+    if (kind == OBNSL_SCORE_BDEU) {
+      a_ij = a_ijk * (double)r;
+      lg_a_ij = lgamma(a_ij);
+    }
+    double t2 = 0.0;
+    for (uint32_t j = lane; j < q; j += 64) {
+      const uint32_t hi = j / w, lo = j - hi * w;
+      const uint32_t base = hi * (r * w) + lo;
+      uint32_t nij = 0;
+      for (uint32_t s = 0; s < r; ++s) nij += cnt[base + s * w];
+      if (nij == 0) continue;
+      if (kind == OBNSL_SCORE_BDEU) t2 += lgamma((double)nij + a_ij) - lg_a_ij;
+      else t2 += (double)nij * log((double)nij);
+    }
+    t2 = wave_sum(t2);
+    double sc = t1 - t2;
+    if (kind == OBNSL_SCORE_BIC) sc -= 0.5 * log(tot) * (double)q * (double)(r - 1);
+    if (lane == 0) out[i] = sc;
+    w *= r;
+  }
+}
+
+// One wavefront per table of a batch: table t pairs row group g (found by
+// binary search on tbl_start) with column group t - tbl_start[g].
+__global__ __launch_bounds__(256) void score_plan_kernel(
+    const uint32_t* __restrict__ counts, const RowGroupDesc* __restrict__ rgs, uint32_t nrgs,
+    const ColGroupDesc* __restrict__ cgs, const uint32_t* __restrict__ card, uint32_t kr,
+    uint32_t kc, uint64_t ntables, int kind, double ess, double* __restrict__ scores) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ntables) return;
+  uint32_t lo = 0, hi = nrgs - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (rgs[mid].tbl_start <= t) lo = mid;
+    else hi = mid - 1;
+  }
+  const RowGroupDesc rg = rgs[lo];
+  const uint32_t gamma = (uint32_t)(t - rg.tbl_start);
+  uint32_t cards[KMAX];
+  uint32_t col_before = 0;
+  if (kc > 0) {
+    const ColGroupDesc cg = cgs[gamma];
+    col_before = cg.col_before;
+    for (uint32_t j = 0; j < kc; ++j) cards[j] = card[cg.vars[j]];
+  }
+  for (uint32_t j = 0; j < kr; ++j) cards[kc + j] = card[rg.vars[j]];
+  const uint32_t k = kr + kc;
+  const uint32_t* cnt = counts + rg.out_off + (uint64_t)col_before * rg.M;
+  const uint64_t rank = rg.rank_part + gamma;
+  score_table(cnt, k, cards, kind, ess, lane, scores + rank * k);
+}
+
+__global__ __launch_bounds__(256) void score_tables_kernel(
+    const uint32_t* __restrict__ counts, const TableDesc* __restrict__ tables, uint64_t ntables,
+    int kind, double ess, double* __restrict__ scores) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ntables) return;
+  const TableDesc td = tables[t];
+  uint32_t cards[KMAX];
+  for (uint32_t j = 0; j < td.k; ++j) cards[j] = td.cards[j];
+  score_table(counts + td.off, td.k, cards, kind, ess, lane, scores + t * td.k);
+}
+
+// ------------------------------------------------------------------ best parents
+__device__ __forceinline__ uint64_t ordered_key(double x) {
+  const uint64_t b = (uint64_t)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// Largest v with C(v, j) <= rank; binom is [(n+1)][KMAX+1].
+__device__ __forceinline__ uint32_t unrank_step(const uint64_t* __restrict__ binom, uint32_t n,
+                                                uint32_t j, uint64_t rank) {
+  uint32_t lo = j - 1, hi = n - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (binom[mid * (KMAX + 1) + j] <= rank) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
+// pass 0: best_key[v] = max ordered score; pass 1: best_id[v] = min id among
+// the entries that reach it, id = (parents << 56) | colex rank of the parent set.
+__global__ __launch_bounds__(256) void best_parents_kernel(
+    const double* __restrict__ scores, uint64_t nsubsets, uint32_t k, uint32_t n,
+    const uint64_t* __restrict__ binom, unsigned long long* __restrict__ best_key,
+    unsigned long long* __restrict__ best_id, int pass) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= nsubsets) return;
+  uint32_t vars[KMAX];
+  uint64_t rem = t;
+  for (uint32_t j = k; j >= 1; --j) {
+    const uint32_t v = unrank_step(binom, n, j, rem);
+    vars[j - 1] = v;
+    rem -= binom[v * (KMAX + 1) + j];
+  }
+  for (uint32_t i = 0; i < k; ++i) {
+    const double sc = scores[t * k + i];
+    if (!(sc > -INFINITY)) continue;  // -inf fill (other shard) or NaN
+    const unsigned long long key = ordered_key(sc);
+    const uint32_t v = vars[i];
+    if (pass == 0) {
+      atomicMax(&best_key[v], key);
+    } else if (key == best_key[v]) {
+      uint64_t prank = 0;  // colex rank of the parent set S \ {v_i}
+      uint32_t pos = 1;
+      for (uint32_t j = 0; j < k; ++j) {
+        if (j == i) continue;
+        prank += binom[vars[j] * (KMAX + 1) + pos];
+        ++pos;
+      }
+      atomicMin(&best_id[v], ((unsigned long long)(k - 1) << 56) | prank);
+    }
+  }
+}
+
+__global__ void fill_u64_kernel(unsigned long long* p, unsigned long long v, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------ host side
+uint64_t binom_host(uint32_t n, uint32_t k) {
+  if (k > n) return 0;
+  if (k > n - k) k = n - k;
+  unsigned __int128 r = 1;
+  for (uint32_t i = 1; i <= k; ++i) {
+    r = r * (n - k + i) / i;
+    if (r > (unsigned __int128)UINT64_MAX) return UINT64_MAX;
+  }
+  return (uint64_t)r;
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { reset(); }
+  void reset() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t ensure(size_t count) {
+    if (count <= n) return hipSuccess;
+    reset();
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  hipError_t upload(const std::vector<T>& h) {
+    hipError_t e = ensure(std::max<size_t>(h.size(), 1));
+    if (e != hipSuccess || h.empty()) return e;
+    return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+  }
+};
+
+struct Batch {
+  DevBuf<RowDesc> rows;
+  DevBuf<uint2> items;
+  DevBuf<RowGroupDesc> rgs;
+  uint32_t nrows = 0, nitems = 0, nrgs = 0;
+  uint64_t ntables = 0, ncells = 0;
+};
+
+struct Plan {
+  uint32_t k = 0, kr = 0, kc = 0;
+  DevBuf<ColDesc> cols;
+  DevBuf<ColGroupDesc> cgs;
+  uint32_t ncols_total = 0;
+  std::vector<std::unique_ptr<Batch>> batches;
+};
+
+}  // namespace
+
+struct obnsl_data {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint64_t N = 0, stride = 0;
+  uint32_t n = 0, wp = 0, total_planes = 0, ones_plane = 0;
+  std::vector<uint32_t> card, plane_base;
+  DevBuf<uint8_t> codes;
+  DevBuf<uint32_t> planes, d_card, d_plane_base, counts;
+  DevBuf<uint64_t> d_binom;
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::unique_ptr<Plan>> plans;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // around each bit-GEMM launch
+  uint32_t ev_used = 0, ev_k = 0;                     // pending pairs and their subset size
+  double acc_ms[OBNSL_MAX_SUBSET + 1] = {0};          // per subset size, since the last reset
+  uint32_t acc_launches[OBNSL_MAX_SUBSET + 1] = {0};
+  ~obnsl_data() {
+    for (auto& e : ev) {
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+  }
+};
+
+namespace {
+
+// Enumerate size-k subsets of {0..n-1} in colex order.
+void enumerate_colex(uint32_t n, uint32_t k, std::vector<std::vector<uint32_t>>& out) {
+  out.clear();
+  if (k > n) return;
+  std::vector<uint32_t> c(k);
+  for (uint32_t i = 0; i < k; ++i) c[i] = i;
+  if (k == 0) {
+    out.push_back(c);
+    return;
+  }
+  for (;;) {
+    out.push_back(c);
+    uint32_t i = 0;
+    for (; i < k; ++i) {
+      const uint32_t lim = (i + 1 < k) ? c[i + 1] : n;
+      if (c[i] + 1 < lim) break;
+    }
+    if (i == k) break;
+    ++c[i];
+    for (uint32_t j = 0; j < i; ++j) c[j] = j;
+  }
+}
+
+obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nshards,
+                        Plan** out) {
+  auto key = std::make_tuple(k, shard, nshards);
+  auto itp = d->plans.find(key);
+  if (itp != d->plans.end()) {
+    *out = itp->second.get();
+    return OBNSL_OK;
+  }
+  auto plan = std::make_unique<Plan>();
+  plan->k = k;
+  plan->kc = k / 2;
+  plan->kr = k - plan->kc;
+  const uint32_t kr = plan->kr, kc = plan->kc, n = d->n;
+
+  // column side: every kc-subset in colex order, cells with the first variable
+  // most significant
+  std::vector<std::vector<uint32_t>> csub;
+  enumerate_colex(n, kc, csub);
+  std::vector<ColGroupDesc> cgs(csub.size());
+  std::vector<ColDesc> cols;
+  {
+    uint64_t total = 0;
+    for (size_t g = 0; g < csub.size(); ++g) {
+      uint64_t cells = 1;
+      for (uint32_t v : csub[g]) cells *= d->card[v];
+      total += cells;
+      if (total > (1u << 27))
+        return fail(OBNSL_ERR_UNSUPPORTED, "column side of the table batch is too large");
+    }
+    cols.reserve(total);
+    uint32_t before = 0;
+    for (size_t g = 0; g < csub.size(); ++g) {
+      ColGroupDesc& cg = cgs[g];
+      std::memset(&cg, 0, sizeof(cg));
+      uint32_t cells = 1;
+      for (uint32_t j = 0; j < kc; ++j) {
+        cg.vars[j] = csub[g][j];
+        cells *= d->card[csub[g][j]];
+      }
+      cg.col_before = before;
+      cg.cells = cells;
+      for (uint32_t cell = 0; cell < cells; ++cell) {
+        ColDesc cd;
+        for (int j = 0; j < KSIDE; ++j) cd.plane[j] = d->ones_plane;
+        uint32_t rem = cell;
+        for (int j = (int)kc - 1; j >= 0; --j) {
+          const uint32_t r = d->card[csub[g][j]];
+          cd.plane[j] = d->plane_base[csub[g][j]] + rem % r;
+          rem /= r;
+        }
+        cols.push_back(cd);
+      }
+      before += cells;
+    }
+  }
+  plan->ncols_total = (uint32_t)cols.size();
+  // columns usable by a row group whose smallest variable is u: those of the
+  // first C(u, kc) column groups
+  std::vector<uint32_t> ncols_below(n + 1, 0);
+  for (uint32_t u = 0; u <= n; ++u) {
+    const uint64_t g = kc == 0 ? 1 : binom_host(u, kc);
+    if (g == 0) ncols_below[u] = 0;
+    else if (g >= cgs.size()) ncols_below[u] = (uint32_t)cols.size();
+    else ncols_below[u] = cgs[g].col_before;
+  }
+
+  // row side: kr-subsets with at least kc variables below them, by smallest
+  // variable (then colex), so that the valid columns of a row tile are a prefix
+  std::vector<std::vector<uint32_t>> rsub_all, rsub;
+  enumerate_colex(n, kr, rsub_all);
+  for (auto& s : rsub_all)
+    if (s[0] >= kc) rsub.push_back(s);
+  std::stable_sort(rsub.begin(), rsub.end(),
+                   [](const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) {
+                     return a[0] < b[0];
+                   });
+  std::vector<uint64_t> cum(rsub.size() + 1, 0);
+  std::vector<uint64_t> Ms(rsub.size());
+  for (size_t g = 0; g < rsub.size(); ++g) {
+    uint64_t M = 1;
+    for (uint32_t v : rsub[g]) M *= d->card[v];
+    if (M > (1u << 24)) return fail(OBNSL_ERR_UNSUPPORTED, "row side of a table is too large");
+    Ms[g] = M;
+    cum[g + 1] = cum[g] + M * ncols_below[rsub[g][0]];
+  }
+  const uint64_t total_cost = cum[rsub.size()];
+  // shard = contiguous run of row groups with equal share of the counters
+  size_t g_lo = 0, g_hi = rsub.size();
+  if (nshards > 1) {
+    const uint64_t lo_c = total_cost / nshards * shard + std::min<uint64_t>(shard, total_cost % nshards);
+    const uint64_t hi_c = total_cost / nshards * (shard + 1) + std::min<uint64_t>(shard + 1, total_cost % nshards);
+    g_lo = std::lower_bound(cum.begin(), cum.end() - 1, lo_c) - cum.begin();
+    g_hi = std::lower_bound(cum.begin(), cum.end() - 1, hi_c) - cum.begin();
+    if (shard == nshards - 1) g_hi = rsub.size();
+    if (shard == 0) g_lo = 0;
+  }
+
+  size_t g = g_lo;
+  while (g < g_hi) {
+    auto b = std::make_unique<Batch>();
+    std::vector<RowDesc> rows;
+    std::vector<RowGroupDesc> rgs;
+    uint64_t off = 0, tables = 0;
+    while (g < g_hi) {
+      const uint64_t M = Ms[g];
+      const uint32_t u1 = rsub[g][0];
+      const uint64_t sz = M * ncols_below[u1];
+      if (off > 0 && off + sz > BATCH_CELL_CAP) break;
+      if (rows.size() + M > (1u << 27))
+        return fail(OBNSL_ERR_UNSUPPORTED, "row side of the table batch is too large");
+      RowGroupDesc rg;
+      std::memset(&rg, 0, sizeof(rg));
+      uint64_t rank_part = 0;
+      for (uint32_t j = 0; j < kr; ++j) {
+        rg.vars[j] = rsub[g][j];
+        rank_part += binom_host(rsub[g][j], kc + j + 1);
+      }
+      rg.out_off = off;
+      rg.rank_part = rank_part;
+      rg.tbl_start = tables;
+      rg.M = (uint32_t)M;
+      rg.ncolgroups = kc == 0 ? 1 : (uint32_t)binom_host(u1, kc);
+      rgs.push_back(rg);
+      for (uint32_t cell = 0; cell < M; ++cell) {
+        RowDesc rd;
+        for (int j = 0; j < KSIDE; ++j) rd.plane[j] = d->ones_plane;
+        uint32_t rem = cell;
+        for (int j = (int)kr - 1; j >= 0; --j) {
+          const uint32_t r = d->card[rsub[g][j]];
+          rd.plane[j] = d->plane_base[rsub[g][j]] + rem % r;
+          rem /= r;
+        }
+        rd.out_base = off + cell;
+        rd.M = (uint32_t)M;
+        rd.ncols = ncols_below[u1];
+        rows.push_back(rd);
+      }
+      off += sz;
+      tables += rg.ncolgroups;
+      ++g;
+    }
+    // tiles: (row tile i, column tile j) for j below the tile's column limit
+    std::vector<std::pair<uint32_t, uint2>> tiles;
+    const uint32_t ntr = (uint32_t)((rows.size() + BM - 1) / BM);
+    for (uint32_t i = 0; i < ntr; ++i) {
+      const size_t last = std::min<size_t>((size_t)(i + 1) * BM, rows.size()) - 1;
+      const uint32_t lim = rows[last].ncols;
+      for (uint32_t j = 0; j * BN < lim; ++j)
+        tiles.push_back({std::min<uint32_t>(lim - j * BN, BN), make_uint2(i, j)});
+    }
+    std::stable_sort(tiles.begin(), tiles.end(),
+                     [](const std::pair<uint32_t, uint2>& a, const std::pair<uint32_t, uint2>& b) {
+                       return a.first > b.first;
+                     });
+    std::vector<uint2> items(tiles.size());
+    for (size_t i = 0; i < tiles.size(); ++i) items[i] = tiles[i].second;
+    b->nrows = (uint32_t)rows.size();
+    b->nitems = (uint32_t)items.size();
+    b->nrgs = (uint32_t)rgs.size();
+    b->ntables = tables;
+    b->ncells = off;
+    HIP_TRY(b->rows.upload(rows));
+    HIP_TRY(b->items.upload(items));
+    HIP_TRY(b->rgs.upload(rgs));
+    plan->batches.push_back(std::move(b));
+  }
+  HIP_TRY(plan->cols.upload(cols));
+  HIP_TRY(plan->cgs.upload(cgs));
+  *out = plan.get();
+  d->plans[key] = std::move(plan);
+  return OBNSL_OK;
+}
+
+// Folds the event pairs of the previous obnsl_score_all into the running
+// per-subset-size totals (waits for them if they are still in flight).
+obnsl_status resolve_events(obnsl_data* d) {
+  for (uint32_t i = 0; i < d->ev_used; ++i) {
+    float t = 0;
+    HIP_TRY(hipEventSynchronize(d->ev[i].second));
+    HIP_TRY(hipEventElapsedTime(&t, d->ev[i].first, d->ev[i].second));
+    d->acc_ms[d->ev_k] += t;
+    d->acc_launches[d->ev_k] += 1;
+  }
+  d->ev_used = 0;
+  return OBNSL_OK;
+}
+
+template <int KR, int KC>
+void launch_bitgemm(obnsl_data* d, const Plan* p, const Batch* b, uint32_t grid,
+                    uint32_t steps_total, uint32_t steps_per_split, int atomics) {
+  hipLaunchKernelGGL((bitgemm_kernel<KR, KC>), dim3(grid), dim3(256), 0, d->stream,
+                     d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
+                     b->items.p, b->nitems, d->counts.p, steps_total, steps_per_split, atomics);
+}
+
+obnsl_status check_kind(obnsl_score_kind kind) {
+  if (kind == OBNSL_SCORE_BDEU || kind == OBNSL_SCORE_BIC) return OBNSL_OK;
+  return fail(OBNSL_ERR_UNSUPPORTED, "Unsupported score type.");
+}
+
+obnsl_status set_device(int device) {
+  HIP_TRY(hipSetDevice(device));
+  return OBNSL_OK;
+}
+
+obnsl_status run_pack(obnsl_data* d) {
+  dim3 grid((d->wp + 255) / 256, d->n + 1);
+  hipLaunchKernelGGL(pack_planes_kernel, grid, dim3(256), 0, d->stream, d->codes.p, d->N,
+                     d->stride, d->n, d->d_card.p, d->d_plane_base.p, d->planes.p, d->wp,
+                     d->ones_plane);
+  HIP_TRY(hipGetLastError());
+  return OBNSL_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+const char* obnsl_last_error(void) { return g_err.c_str(); }
+int obnsl_abi_version(void) { return 1; }
+
+obnsl_status obnsl_device_count(int* count) {
+  if (!count) return fail(OBNSL_ERR_INVALID_ARGUMENT, "count is null");
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  *count = c;
+  return OBNSL_OK;
+}
+
+uint64_t obnsl_binomial(uint32_t n, uint32_t k) { return binom_host(n, k); }
+
+obnsl_status obnsl_unrank(uint64_t rank, uint32_t k, uint32_t* out) {
+  if (k > 64 || !out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "bad unrank arguments");
+  for (uint32_t j = k; j >= 1; --j) {
+    uint32_t v = j - 1;
+    while (binom_host(v + 1, j) <= rank) ++v;
+    out[j - 1] = v;
+    rank -= binom_host(v, j);
+  }
+  return OBNSL_OK;
+}
+
+uint64_t obnsl_rank(const uint32_t* v, uint32_t k) {
+  uint64_t r = 0;
+  for (uint32_t j = 0; j < k; ++j) r += binom_host(v[j], j + 1);
+  return r;
+}
+
+obnsl_status obnsl_data_create(const uint8_t* codes, uint64_t num_rows, uint64_t col_stride,
+                               uint32_t num_vars, const uint32_t* cardinalities, int device,
+                               int codes_on_device, obnsl_data** out) {
+  if (!out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  if (!codes || !cardinalities || num_vars == 0 || num_rows == 0)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "empty data set");
+  if (col_stride < num_rows)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "col_stride is smaller than num_rows");
+  if (num_rows >= (1ull << 32))
+    return fail(OBNSL_ERR_UNSUPPORTED, "more than 2^32-1 rows");
+  if (num_vars > 65535) return fail(OBNSL_ERR_UNSUPPORTED, "more than 65535 variables");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(OBNSL_ERR_NO_DEVICE, "no HIP device available: the local-score engine has no CPU path");
+  if (device < 0 || device >= ndev)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+
+  auto d = std::make_unique<obnsl_data>();
+  d->device = device;
+  d->N = num_rows;
+  d->n = num_vars;
+  d->card.assign(cardinalities, cardinalities + num_vars);
+  d->plane_base.resize(num_vars);
+  uint64_t planes = 0;
+  for (uint32_t v = 0; v < num_vars; ++v) {
+    if (d->card[v] == 0 || d->card[v] > 256)
+      return fail(OBNSL_ERR_INVALID_ARGUMENT, "cardinality must be in [1, 256]");
+    d->plane_base[v] = (uint32_t)planes;
+    planes += d->card[v];
+  }
+  d->total_planes = (uint32_t)planes;
+  d->ones_plane = d->total_planes;
+  const uint64_t words = (num_rows + 31) / 32;
+  d->wp = (uint32_t)((words + 63) / 64 * 64);
+  d->stride = (uint64_t)d->wp * 32;
+  if ((planes + 1) * (uint64_t)d->wp >= (1ull << 32))
+    return fail(OBNSL_ERR_UNSUPPORTED, "row bitmaps exceed 2^32 words");
+
+  HIP_TRY(d->codes.ensure((size_t)d->stride * num_vars));
+  HIP_TRY(hipMemset(d->codes.p, 0, (size_t)d->stride * num_vars));
+  HIP_TRY(hipMemcpy2D(d->codes.p, d->stride, codes, col_stride, num_rows, num_vars,
+                      codes_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  HIP_TRY(d->planes.ensure((size_t)(planes + 1) * d->wp));
+  HIP_TRY(d->d_card.upload(d->card));
+  HIP_TRY(d->d_plane_base.upload(d->plane_base));
+  std::vector<uint64_t> binom((size_t)(num_vars + 1) * (KMAX + 1));
+  for (uint32_t v = 0; v <= num_vars; ++v)
+    for (uint32_t j = 0; j <= (uint32_t)KMAX; ++j) binom[(size_t)v * (KMAX + 1) + j] = binom_host(v, j);
+  HIP_TRY(d->d_binom.upload(binom));
+  obnsl_status st = run_pack(d.get());
+  if (st != OBNSL_OK) return st;
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  *out = d.release();
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_data_destroy(obnsl_data* d) {
+  if (!d) return OBNSL_OK;
+  (void)hipSetDevice(d->device);
+  (void)hipDeviceSynchronize();
+  delete d;
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_data_set_stream(obnsl_data* d, void* hip_stream) {
+  if (!d) return fail(OBNSL_ERR_INVALID_ARGUMENT, "data is null");
+  d->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_data_pack(obnsl_data* d) {
+  if (!d) return fail(OBNSL_ERR_INVALID_ARGUMENT, "data is null");
+  obnsl_status st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  return run_pack(d);
+}
+
+obnsl_status obnsl_num_subsets(const obnsl_data* d, uint32_t k, uint64_t* num) {
+  if (!d || !num) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  *num = binom_host(d->n, k);
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_count(obnsl_data* d, const uint32_t* var_ids, uint32_t k,
+                         uint64_t* counts_out, uint64_t cap) {
+  if (!d || !counts_out || (k && !var_ids)) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (k > KMAX) return fail(OBNSL_ERR_UNSUPPORTED, "subset larger than OBNSL_MAX_SUBSET");
+  for (uint32_t i = 0; i < k; ++i) {
+    if (var_ids[i] >= d->n) return fail(OBNSL_ERR_OUT_OF_RANGE, "variable id out of range");
+    if (i && var_ids[i] < var_ids[i - 1])
+      return fail(OBNSL_ERR_INVALID_ARGUMENT, "var_ids must be sorted");
+  }
+  uint64_t cells = 1;
+  std::vector<uint32_t> pbase(KMAX, 0), cards(KMAX, 1);
+  for (uint32_t i = 0; i < k; ++i) {
+    pbase[i] = d->plane_base[var_ids[i]];
+    cards[i] = d->card[var_ids[i]];
+    cells *= cards[i];
+    if (cells > (1ull << 26)) return fail(OBNSL_ERR_UNSUPPORTED, "table has more than 2^26 cells");
+  }
+  if (cells > cap) return fail(OBNSL_ERR_INVALID_ARGUMENT, "counts_out is too small");
+  obnsl_status st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  DevBuf<uint32_t> dp, dc, dcnt;
+  HIP_TRY(dp.upload(pbase));
+  HIP_TRY(dc.upload(cards));
+  HIP_TRY(dcnt.ensure(cells));
+  HIP_TRY(hipMemsetAsync(dcnt.p, 0, cells * sizeof(uint32_t), d->stream));
+  const uint32_t gx = std::min<uint32_t>((d->wp + 255) / 256, 64);
+  const uint32_t gy = (uint32_t)std::min<uint64_t>(cells, 1024);
+  hipLaunchKernelGGL(count_single_kernel, dim3(gx, gy), dim3(256), 0, d->stream, d->planes.p,
+                     d->wp, k, dp.p, dc.p, (uint32_t)cells, dcnt.p, d->ones_plane);
+  HIP_TRY(hipGetLastError());
+  std::vector<uint32_t> h(cells);
+  HIP_TRY(hipMemcpyAsync(h.data(), dcnt.p, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  for (uint64_t i = 0; i < cells; ++i) counts_out[i] = h[i];
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_local_score(int device, const uint64_t* counts, const uint32_t* cards,
+                               uint32_t k, uint32_t child_idx, obnsl_score_kind kind,
+                               double ess, double* score_out) {
+  if (!counts || !score_out || (k && !cards)) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (k == 0 || k > KMAX) return fail(OBNSL_ERR_UNSUPPORTED, "subset size must be in [1, OBNSL_MAX_SUBSET]");
+  if (child_idx >= k) return fail(OBNSL_ERR_INVALID_ARGUMENT, "child_var not present in contingency table");
+  obnsl_status st = check_kind(kind);
+  if (st != OBNSL_OK) return st;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(OBNSL_ERR_NO_DEVICE, "no HIP device available: the local-score engine has no CPU path");
+  if (device < 0 || device >= ndev) return fail(OBNSL_ERR_INVALID_ARGUMENT, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  TableDesc td;
+  std::memset(&td, 0, sizeof(td));
+  td.k = k;
+  uint64_t cells = 1;
+  for (uint32_t i = 0; i < k; ++i) {
+    if (cards[i] == 0) return fail(OBNSL_ERR_INVALID_ARGUMENT, "zero cardinality");
+    td.cards[i] = cards[i];
+    cells *= cards[i];
+    if (cells > (1ull << 26)) return fail(OBNSL_ERR_UNSUPPORTED, "table has more than 2^26 cells");
+  }
+  std::vector<uint32_t> h(cells);
+  for (uint64_t i = 0; i < cells; ++i) {
+    if (counts[i] >= (1ull << 32)) return fail(OBNSL_ERR_UNSUPPORTED, "count exceeds 2^32-1");
+    h[i] = (uint32_t)counts[i];
+  }
+  DevBuf<uint32_t> dcnt;
+  DevBuf<TableDesc> dtd;
+  DevBuf<double> dout;
+  HIP_TRY(dcnt.upload(h));
+  HIP_TRY(dtd.upload(std::vector<TableDesc>{td}));
+  HIP_TRY(dout.ensure(KMAX));
+  hipLaunchKernelGGL(score_tables_kernel, dim3(1), dim3(256), 0, nullptr, dcnt.p, dtd.p,
+                     (uint64_t)1, (int)kind, ess, dout.p);
+  HIP_TRY(hipGetLastError());
+  double res[KMAX];
+  HIP_TRY(hipMemcpy(res, dout.p, k * sizeof(double), hipMemcpyDeviceToHost));
+  *score_out = res[child_idx];
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, uint32_t k,
+                             uint32_t shard, uint32_t num_shards, double* scores_out,
+                             int out_on_device) {
+  if (!d || !scores_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (k == 0 || k > KMAX || k > d->n)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "subset size must be in [1, min(num_vars, OBNSL_MAX_SUBSET)]");
+  if (num_shards == 0 || shard >= num_shards)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "shard must be in [0, num_shards)");
+  if (!out_on_device && num_shards != 1)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "sharded scoring needs out_on_device");
+  obnsl_status st = check_kind(kind);
+  if (st != OBNSL_OK) return st;
+  st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  Plan* plan = nullptr;
+  st = build_plan(d, k, shard, num_shards, &plan);
+  if (st != OBNSL_OK) return st;
+
+  const uint64_t nsub = binom_host(d->n, k);
+  DevBuf<double> tmp;
+  double* d_scores = scores_out;
+  if (!out_on_device) {
+    HIP_TRY(tmp.ensure(nsub * k));
+    d_scores = tmp.p;
+  }
+  st = resolve_events(d);
+  if (st != OBNSL_OK) return st;
+  d->ev_k = k;
+  const uint32_t steps_total = d->wp / KCW;
+  for (auto& bp : plan->batches) {
+    Batch* b = bp.get();
+    if (b->nitems == 0 || b->ntables == 0) continue;
+    HIP_TRY(d->counts.ensure(b->ncells));
+    // split the contraction when there are too few tiles to fill the chip
+    uint32_t ksplit = 1;
+    const uint32_t want = 256 * 8;
+    if (b->nitems < want) ksplit = std::min<uint32_t>((want + b->nitems - 1) / b->nitems, steps_total);
+    const uint32_t sps = (steps_total + ksplit - 1) / ksplit;
+    ksplit = (steps_total + sps - 1) / sps;
+    const int atomics = ksplit > 1;
+    if (atomics) HIP_TRY(hipMemsetAsync(d->counts.p, 0, b->ncells * sizeof(uint32_t), d->stream));
+    if (d->ev_used == d->ev.size()) {
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      d->ev.push_back({e0, e1});
+    }
+    auto& ev = d->ev[d->ev_used++];
+    HIP_TRY(hipEventRecord(ev.first, d->stream));
+    const uint32_t grid = b->nitems * ksplit;
+    const uint32_t kcn = plan->kc == 0 ? 1 : plan->kc;  // kc == 0: the single ONES column
+    switch (plan->kr * 10 + kcn) {
+      case 11: launch_bitgemm<1, 1>(d, plan, b, grid, steps_total, sps, atomics); break;
+      case 21: launch_bitgemm<2, 1>(d, plan, b, grid, steps_total, sps, atomics); break;
+      case 22: launch_bitgemm<2, 2>(d, plan, b, grid, steps_total, sps, atomics); break;
+      case 32: launch_bitgemm<3, 2>(d, plan, b, grid, steps_total, sps, atomics); break;
+      case 33: launch_bitgemm<3, 3>(d, plan, b, grid, steps_total, sps, atomics); break;
+      case 43: launch_bitgemm<4, 3>(d, plan, b, grid, steps_total, sps, atomics); break;
+      case 44: launch_bitgemm<4, 4>(d, plan, b, grid, steps_total, sps, atomics); break;
+      default: return fail(OBNSL_ERR_RUNTIME, "internal: no bit-GEMM instance");
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, d->stream));
+    const uint32_t sgrid = (uint32_t)((b->ntables + 3) / 4);
+    hipLaunchKernelGGL(score_plan_kernel, dim3(sgrid), dim3(256), 0, d->stream, d->counts.p,
+                       b->rgs.p, b->nrgs, plan->cgs.p, d->d_card.p, plan->kr, plan->kc,
+                       b->ntables, (int)kind, ess, d_scores);
+    HIP_TRY(hipGetLastError());
+  }
+  if (!out_on_device) {
+    HIP_TRY(hipMemcpyAsync(scores_out, d_scores, nsub * k * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+  }
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_score_subsets(obnsl_data* d, obnsl_score_kind kind, double ess,
+                                 const uint32_t* subsets, uint32_t k, uint64_t m,
+                                 double* scores_out) {
+  if (!d || !subsets || !scores_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (k == 0 || k > KMAX) return fail(OBNSL_ERR_INVALID_ARGUMENT, "subset size must be in [1, OBNSL_MAX_SUBSET]");
+  obnsl_status st = check_kind(kind);
+  if (st != OBNSL_OK) return st;
+  st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  std::vector<TableDesc> tds(m);
+  std::vector<uint32_t> pb(m * KMAX, 0), cd(m * KMAX, 1);
+  uint64_t off = 0;
+  for (uint64_t t = 0; t < m; ++t) {
+    TableDesc& td = tds[t];
+    std::memset(&td, 0, sizeof(td));
+    td.k = k;
+    td.off = off;
+    uint64_t cells = 1;
+    for (uint32_t i = 0; i < k; ++i) {
+      const uint32_t v = subsets[t * k + i];
+      if (v >= d->n) return fail(OBNSL_ERR_OUT_OF_RANGE, "variable id out of range");
+      if (i && v <= subsets[t * k + i - 1])
+        return fail(OBNSL_ERR_INVALID_ARGUMENT, "var_ids must be sorted");
+      td.cards[i] = d->card[v];
+      pb[t * KMAX + i] = d->plane_base[v];
+      cd[t * KMAX + i] = d->card[v];
+      cells *= d->card[v];
+      if (cells > (1ull << 26)) return fail(OBNSL_ERR_UNSUPPORTED, "table has more than 2^26 cells");
+    }
+    off += cells;
+  }
+  DevBuf<uint32_t> dpb, dcd, dcnt;
+  DevBuf<TableDesc> dtd;
+  DevBuf<double> dout;
+  HIP_TRY(dpb.upload(pb));
+  HIP_TRY(dcd.upload(cd));
+  HIP_TRY(dtd.upload(tds));
+  HIP_TRY(dcnt.ensure(std::max<uint64_t>(off, 1)));
+  HIP_TRY(dout.ensure(std::max<uint64_t>(m * k, 1)));
+  HIP_TRY(hipMemsetAsync(dcnt.p, 0, off * sizeof(uint32_t), d->stream));
+  const uint32_t gx = std::min<uint32_t>((d->wp + 255) / 256, 64);
+  for (uint64_t t = 0; t < m; ++t) {
+    const uint32_t cells = (uint32_t)((t + 1 < m ? tds[t + 1].off : off) - tds[t].off);
+    hipLaunchKernelGGL(count_single_kernel, dim3(gx, std::min<uint32_t>(cells, 1024)), dim3(256),
+                       0, d->stream, d->planes.p, d->wp, k, dpb.p + t * KMAX, dcd.p + t * KMAX,
+                       cells, dcnt.p + tds[t].off, d->ones_plane);
+  }
+  HIP_TRY(hipGetLastError());
+  if (m) {
+    hipLaunchKernelGGL(score_tables_kernel, dim3((uint32_t)((m + 3) / 4)), dim3(256), 0, d->stream,
+                       dcnt.p, dtd.p, m, (int)kind, ess, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(scores_out, dout.p, m * k * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
+                                uint32_t max_parents, double* best_score,
+                                uint32_t* best_size, uint64_t* best_rank) {
+  if (!d || !d_scores || !best_score || !best_size || !best_rank)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (max_parents + 1 > (uint32_t)KMAX || max_parents + 1 > d->n)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
+  obnsl_status st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  DevBuf<unsigned long long> key, id;
+  HIP_TRY(key.ensure(d->n));
+  HIP_TRY(id.ensure(d->n));
+  const uint32_t gb = (d->n + 255) / 256;
+  hipLaunchKernelGGL(fill_u64_kernel, dim3(gb), dim3(256), 0, d->stream, key.p, 0ull, d->n);
+  hipLaunchKernelGGL(fill_u64_kernel, dim3(gb), dim3(256), 0, d->stream, id.p, ~0ull, d->n);
+  for (int pass = 0; pass < 2; ++pass)
+    for (uint32_t k = 1; k <= max_parents + 1; ++k) {
+      const uint64_t nsub = binom_host(d->n, k);
+      hipLaunchKernelGGL(best_parents_kernel, dim3((uint32_t)((nsub + 255) / 256)), dim3(256), 0,
+                         d->stream, d_scores[k - 1], nsub, k, d->n, d->d_binom.p, key.p, id.p, pass);
+    }
+  HIP_TRY(hipGetLastError());
+  std::vector<unsigned long long> hk(d->n), hi(d->n);
+  HIP_TRY(hipMemcpyAsync(hk.data(), key.p, d->n * 8, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(hi.data(), id.p, d->n * 8, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  for (uint32_t v = 0; v < d->n; ++v) {
+    if (hk[v] == 0) {  // nothing scored for this node in this shard
+      best_score[v] = -INFINITY;
+      best_size[v] = 0;
+      best_rank[v] = 0;
+      continue;
+    }
+    const uint64_t kbits = hk[v];
+    const uint64_t bits = (kbits >> 63) ? (kbits & 0x7fffffffffffffffull) : ~kbits;
+    double sc;
+    std::memcpy(&sc, &bits, 8);
+    best_score[v] = sc;
+    best_size[v] = (uint32_t)(hi[v] >> 56);
+    best_rank[v] = hi[v] & ((1ull << 56) - 1);
+  }
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_kernel_time(obnsl_data* d, uint32_t k, double* total_ms, uint32_t* launches,
+                               int reset) {
+  if (!d || !total_ms || !launches || k == 0 || k > (uint32_t)KMAX)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "bad obnsl_kernel_time arguments");
+  obnsl_status st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  st = resolve_events(d);
+  if (st != OBNSL_OK) return st;
+  *total_ms = d->acc_ms[k];
+  *launches = d->acc_launches[k];
+  if (reset)
+    for (int i = 0; i <= KMAX; ++i) {
+      d->acc_ms[i] = 0;
+      d->acc_launches[i] = 0;
+    }
+  return OBNSL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+"""ctypes view of the C ABI in include/obnsl_engine.h (libobnsl_engine.so).
+
+This is plumbing for the benchmark and the parity tests, which call the engine
+exactly as a foreign-language host would: plain pointers and sizes.  There is
+no CPU fallback here: if the library is missing, import fails; if no HIP device
+is present, every compute call raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libobnsl_engine.so")
+
+BDEU, K2, BIC, AIC = 0, 1, 2, 3
+MAX_SUBSET = 8
+
+_STATUS_EXC = {1: ValueError, 2: IndexError, 3: RuntimeError, 4: RuntimeError, 5: ValueError}
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol include/obnsl_engine.h declares
+SIGNATURES = {
+    "obnsl_last_error": (ctypes.c_char_p, []),
+    "obnsl_abi_version": (ctypes.c_int, []),
+    "obnsl_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "obnsl_data_create": (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                                         _u32p, ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(_vp)]),
+    "obnsl_data_destroy": (ctypes.c_int, [_vp]),
+    "obnsl_data_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "obnsl_data_pack": (ctypes.c_int, [_vp]),
+    "obnsl_count": (ctypes.c_int, [_vp, _u32p, ctypes.c_uint32, _u64p, ctypes.c_uint64]),
+    "obnsl_local_score": (ctypes.c_int, [ctypes.c_int, _u64p, _u32p, ctypes.c_uint32,
+                                         ctypes.c_uint32, ctypes.c_int, ctypes.c_double, _f64p]),
+    "obnsl_score_all": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
+                                       ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_int]),
+    "obnsl_num_subsets": (ctypes.c_int, [_vp, ctypes.c_uint32, _u64p]),
+    "obnsl_score_subsets": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, _u32p,
+                                           ctypes.c_uint32, ctypes.c_uint64, _f64p]),
+    "obnsl_best_parents": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _f64p,
+                                          _u32p, _u64p]),
+    "obnsl_binomial": (ctypes.c_uint64, [ctypes.c_uint32, ctypes.c_uint32]),
+    "obnsl_unrank": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, _u32p]),
+    "obnsl_rank": (ctypes.c_uint64, [_u32p, ctypes.c_uint32]),
+    "obnsl_kernel_time": (ctypes.c_int, [_vp, ctypes.c_uint32, _f64p, _u32p, ctypes.c_int]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make` (hipcc, gfx950)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def _check(status):
+    if status != 0:
+        msg = lib.obnsl_last_error().decode()
+        raise _STATUS_EXC.get(status, RuntimeError)(msg)
+
+
+def device_count():
+    c = ctypes.c_int(0)
+    _check(lib.obnsl_device_count(ctypes.byref(c)))
+    return c.value
+
+
+def binomial(n, k):
+    return int(lib.obnsl_binomial(n, k))
+
+
+def unrank(rank, k):
+    out = (ctypes.c_uint32 * max(k, 1))()
+    _check(lib.obnsl_unrank(rank, k, out))
+    return [int(out[i]) for i in range(k)]
+
+
+def rank(var_ids):
+    a = (ctypes.c_uint32 * max(len(var_ids), 1))(*var_ids)
+    return int(lib.obnsl_rank(a, len(var_ids)))
+
+
+def local_score(counts, cards, child_idx, kind=BDEU, ess=1.0, device=0):
+    c = np.ascontiguousarray(counts, dtype=np.uint64)
+    cd = np.ascontiguousarray(cards, dtype=np.uint32)
+    out = ctypes.c_double(0.0)
+    _check(lib.obnsl_local_score(device, c.ctypes.data_as(_u64p), cd.ctypes.data_as(_u32p),
+                                 len(cd), child_idx, kind, ess, ctypes.byref(out)))
+    return out.value
+
+
+class Data:
+    """Device-resident data set (obnsl_data).  `codes`: uint8[n_vars, N] numpy
+    array (host) or a (device_ptr, n_vars, N, col_stride) tuple."""
+
+    def __init__(self, codes, card, device=0):
+        card = np.ascontiguousarray(card, dtype=np.uint32)
+        self._h = _vp()
+        if isinstance(codes, tuple):
+            ptr, n, N, stride = codes
+            on_dev = 1
+        else:
+            codes = np.ascontiguousarray(codes, dtype=np.uint8)
+            n, N = codes.shape
+            stride = N
+            ptr = codes.ctypes.data
+            on_dev = 0
+        self.n, self.N, self.card, self.device = int(n), int(N), card, device
+        _check(lib.obnsl_data_create(ptr, N, stride, n, card.ctypes.data_as(_u32p), device,
+                                     on_dev, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib.obnsl_data_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        _check(lib.obnsl_data_set_stream(self._h, stream_handle))
+
+    def pack(self):
+        _check(lib.obnsl_data_pack(self._h))
+
+    def num_subsets(self, k):
+        return binomial(self.n, k)
+
+    def count(self, var_ids):
+        v = np.ascontiguousarray(var_ids, dtype=np.uint32)
+        cells = 1
+        for i in v:
+            if int(i) < self.n:
+                cells *= int(self.card[int(i)])
+        out = np.zeros(max(cells, 1), dtype=np.uint64)
+        _check(lib.obnsl_count(self._h, v.ctypes.data_as(_u32p), len(v),
+                               out.ctypes.data_as(_u64p), len(out)))
+        return out
+
+    def score_all(self, k, kind=BDEU, ess=1.0):
+        """float64 [C(n,k), k] on the host."""
+        T = self.num_subsets(k)
+        out = np.zeros((T, k), dtype=np.float64)
+        _check(lib.obnsl_score_all(self._h, kind, ess, k, 0, 1, out.ctypes.data, 0))
+        return out
+
+    def score_all_device(self, k, out_ptr, kind=BDEU, ess=1.0, shard=0, num_shards=1):
+        """Asynchronous; out_ptr is a device pointer to C(n,k)*k doubles."""
+        _check(lib.obnsl_score_all(self._h, kind, ess, k, shard, num_shards, out_ptr, 1))
+
+    def score_subsets(self, subsets, kind=BDEU, ess=1.0):
+        s = np.ascontiguousarray(subsets, dtype=np.uint32)
+        m, k = s.shape
+        out = np.zeros((m, k), dtype=np.float64)
+        _check(lib.obnsl_score_subsets(self._h, kind, ess, s.ctypes.data_as(_u32p), k, m,
+                                       out.ctypes.data_as(_f64p)))
+        return out
+
+    def best_parents(self, score_ptrs, max_parents):
+        """score_ptrs[k-1]: device pointer of the size-k score table."""
+        arr = (_vp * len(score_ptrs))(*score_ptrs)
+        sc = np.zeros(self.n, dtype=np.float64)
+        sz = np.zeros(self.n, dtype=np.uint32)
+        rk = np.zeros(self.n, dtype=np.uint64)
+        _check(lib.obnsl_best_parents(self._h, arr, max_parents, sc.ctypes.data_as(_f64p),
+                                      sz.ctypes.data_as(_u32p), rk.ctypes.data_as(_u64p)))
+        return sc, sz, rk
+
+    def kernel_time(self, k, reset=False):
+        """(total ms, launches) of the size-k counting kernel since the last reset."""
+        ms = ctypes.c_double(0.0)
+        n = ctypes.c_uint32(0)
+        _check(lib.obnsl_kernel_time(self._h, k, ctypes.byref(ms), ctypes.byref(n), int(reset)))
+        return ms.value, n.value

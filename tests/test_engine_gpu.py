@@ -1,0 +1,226 @@
+"""GPU parity tests: the HIP engine, called through its C ABI (ctypes), against
+the committed reference outputs (tests/golden) and the plain-C oracle.
+
+Bar: counts bit-exact; scores within 1e-9 relative (the engine evaluates lgamma
+with the device math library, the reference with glibc, and sums in a different
+order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-9
+
+
+def rel_err(have, want):
+    have = np.asarray(have, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    return float(np.max(np.abs(have - want) / np.maximum(np.abs(want), 1e-300)))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from openbnsl_amd import engine as e
+    assert e.device_count() >= 1, "GPU tests need a HIP device"
+    return e
+
+
+@pytest.mark.parametrize("frame", ["asia5k", "mixed3k", "lexi500"])
+def test_golden_counts_and_scores(engine, golden, frame):
+    meta, arrays = golden
+    rec = meta[frame]
+    codes = arrays[frame + "_codes"]
+    card = np.array(rec["num_of_values"], dtype=np.uint32)
+    d = engine.Data(codes, card)
+    for tb in rec["tables"]:
+        vs = tb["var_ids"]
+        cnt = d.count(vs)
+        got = {str(i): int(c) for i, c in enumerate(cnt) if c}
+        assert got == tb["counts"], (frame, vs)
+        if not vs:
+            continue
+        for ess, hexes in tb["scores"].items():
+            want = [float.fromhex(h) for h in hexes]
+            have = [engine.local_score(cnt, card[vs], ci, engine.BDEU, float(ess))
+                    for ci in range(len(vs))]
+            assert rel_err(have, want) <= REL, (frame, vs, ess, have, want)
+            if len(vs) <= engine.MAX_SUBSET:
+                have2 = d.score_subsets([vs], engine.BDEU, float(ess))[0]
+                assert rel_err(have2, want) <= REL
+    d.close()
+
+
+def test_asia_full_score_table_matches_reference(engine, golden):
+    from openbnsl_amd import synth
+    meta, _ = golden
+    rec = meta["asia100k_full"]
+    codes, card, _ = synth.asia(100_000, seed=0)
+    d = engine.Data(codes, card)
+    for k in (1, 2, 3):
+        want = np.array([[float.fromhex(x) for x in row] for row in rec["scores_by_size"][str(k)]])
+        have = d.score_all(k)
+        assert have.shape == want.shape
+        assert rel_err(have, want) <= REL
+    d.close()
+
+
+@pytest.mark.parametrize("cards,N,seed", [
+    ([2, 3, 4, 2, 3, 4, 3, 2, 4, 3, 2, 2], 20_000, 0),   # mixed, N % 32 == 0
+    ([2, 2, 3, 3, 4, 4, 2, 3], 1_001, 1),                 # ragged tail
+    ([4, 4, 4, 4, 4, 4], 33, 2),                          # almost empty tables
+    ([3, 2, 5, 7, 2, 3, 6], 5_000, 3),                    # cardinalities above 4
+])
+def test_score_all_matches_oracle(engine, cards, N, seed):
+    import oracle
+    from openbnsl_amd import synth
+    codes, card, _, _ = synth.random_bn(cards, N, seed=seed, min_prob=0.02)
+    d = engine.Data(codes, card)
+    n = len(cards)
+    for k in range(1, min(n, 6) + 1):
+        want = oracle.score_all(codes, card, k, oracle.BDEU, 1.0, nthreads=4)
+        have = d.score_all(k)
+        assert rel_err(have, want) <= REL, (cards, N, k)
+        subs = oracle.enumerate_subsets(n, k)
+        for t in range(0, len(subs), max(1, len(subs) // 7)):
+            assert np.array_equal(d.count(subs[t]), oracle.count(codes, card, subs[t]))
+    for k in (2, 3):
+        want = oracle.score_all(codes, card, k, oracle.BIC, 1.0, nthreads=4)
+        assert rel_err(d.score_all(k, engine.BIC), want) <= REL
+        want = oracle.score_all(codes, card, k, oracle.BDEU, 10.0, nthreads=4)
+        assert rel_err(d.score_all(k, engine.BDEU, 10.0), want) <= REL
+    d.close()
+
+
+def test_constant_column_and_single_row(engine):
+    import oracle
+    codes = np.array([[0, 0, 0, 0, 0], [0, 1, 0, 1, 1], [2, 1, 0, 0, 2]], dtype=np.uint8)
+    card = np.array([1, 2, 3], dtype=np.uint32)
+    d = engine.Data(codes, card)
+    for k in (1, 2, 3):
+        assert rel_err(d.score_all(k), oracle.score_all(codes, card, k)) <= REL
+    assert d.count([]).tolist() == [5]
+    d.close()
+    one = np.array([[1], [0]], dtype=np.uint8)
+    d = engine.Data(one, [2, 1])
+    assert d.count([0, 1]).tolist() == [0, 1]
+    d.close()
+
+
+def test_score_subsets_matches_score_all(engine):
+    import oracle
+    from openbnsl_amd import synth
+    codes, card, _, _ = synth.random_bn([2, 3, 4, 2, 3, 2, 4], 4_000, seed=5)
+    d = engine.Data(codes, card)
+    for k in (1, 3, 4):
+        subs = oracle.enumerate_subsets(7, k)
+        full = d.score_all(k)
+        pick = subs[::3]
+        assert np.array_equal(d.score_subsets(pick), full[::3])
+    d.close()
+
+
+def test_sharded_scores_cover_everything_once(engine):
+    torch = pytest.importorskip("torch")
+    import oracle
+    from openbnsl_amd import synth
+    codes, card, _, _ = synth.random_bn([2, 3, 4, 2, 3, 4, 3, 2, 4, 3], 6_000, seed=6)
+    d = engine.Data(codes, card)
+    for k in (1, 2, 3, 4):
+        want = oracle.score_all(codes, card, k, nthreads=4)
+        T = d.num_subsets(k)
+        filled = torch.zeros(T * k, dtype=torch.float64, device="cuda")
+        for nsh in (3,):
+            parts = []
+            for sh in range(nsh):
+                buf = torch.full((T * k,), float("-inf"), dtype=torch.float64, device="cuda")
+                d.score_all_device(k, buf.data_ptr(), shard=sh, num_shards=nsh)
+                torch.cuda.synchronize()
+                parts.append(buf)
+            stack = torch.stack(parts)
+            assert int((stack > float("-inf")).sum(dim=0).min()) == 1   # each entry exactly once
+            assert int((stack > float("-inf")).sum(dim=0).max()) == 1
+            filled = stack.max(dim=0).values
+        assert rel_err(filled.cpu().numpy().reshape(T, k), want) <= REL
+    d.close()
+
+
+def test_best_parents_matches_bruteforce(engine):
+    torch = pytest.importorskip("torch")
+    import oracle
+    from openbnsl_amd import synth
+    codes, card, _, _ = synth.random_bn([2, 3, 4, 2, 3, 4, 3, 2, 4], 8_000, seed=7)
+    n, mp = 9, 3
+    d = engine.Data(codes, card)
+    bufs, want_best = [], {}
+    for k in range(1, mp + 2):
+        T = d.num_subsets(k)
+        buf = torch.empty(T * k, dtype=torch.float64, device="cuda")
+        d.score_all_device(k, buf.data_ptr())
+        bufs.append(buf)
+    torch.cuda.synchronize()
+    sc, sz, rk = d.best_parents([b.data_ptr() for b in bufs], mp)
+    for k in range(1, mp + 2):
+        subs = oracle.enumerate_subsets(n, k)
+        tab = bufs[k - 1].cpu().numpy().reshape(-1, k)
+        for t, s in enumerate(subs):
+            for i, v in enumerate(s):
+                ps = [int(x) for x in s if x != v]
+                key = (tab[t, i], -(k - 1), -engine.rank(ps))
+                if int(v) not in want_best or key > want_best[int(v)][0]:
+                    want_best[int(v)] = (key, ps)
+    for v in range(n):
+        key, ps = want_best[v]
+        assert sc[v] == key[0]
+        assert int(sz[v]) == len(ps)
+        assert engine.unrank(int(rk[v]), int(sz[v])) == ps
+    d.close()
+
+
+def test_error_behaviour(engine, golden):
+    meta, arrays = golden
+    codes = arrays["asia5k_codes"]
+    d = engine.Data(codes, [2] * 8)
+    # reference messages: tests/golden/reference_outputs.json "errors"
+    with pytest.raises(ValueError, match=meta["errors"]["unsorted_var_ids"][1]):
+        d.count([3, 1])
+    with pytest.raises(ValueError, match="Unsupported score type"):
+        d.score_all(2, engine.K2)
+    with pytest.raises(ValueError, match="Unsupported score type"):
+        engine.local_score([1, 2, 3, 4], [2, 2], 0, engine.AIC)
+    with pytest.raises(ValueError, match=meta["errors"]["child_not_in_table"][1]):
+        engine.local_score([1, 2, 3, 4], [2, 2], 2)
+    with pytest.raises(IndexError):
+        d.count([1, 99])
+    d.close()
+
+
+def test_alarm_shape_full_size_properties(engine):
+    """BASELINE config 2 at full size (37 vars, 1e6 rows, subsets up to 4):
+    sampled tables bit-exact vs the oracle, sampled scores within tolerance,
+    and the size-independent invariant sum(counts) == N
+    (reference: pytest/base/test_contingency_table.py:18-27)."""
+    import oracle
+    from openbnsl_amd import synth
+    codes, card, _ = synth.alarm_shaped(1_000_000, seed=0)
+    d = engine.Data(codes, card)
+    rng = np.random.default_rng(0)
+    scores4 = d.score_all(4)
+    assert scores4.shape == (66045, 4)
+    assert np.all(np.isfinite(scores4)) and np.all(scores4 < 0)
+    subs = oracle.enumerate_subsets(37, 4)
+    for t in rng.choice(len(subs), size=12, replace=False):
+        vs = subs[t]
+        cnt = d.count(vs)
+        ocnt = oracle.count(codes, card, vs)
+        assert np.array_equal(cnt, ocnt)
+        assert int(cnt.sum()) == 1_000_000
+        want = [oracle.local_score(ocnt, card[vs], ci) for ci in range(4)]
+        assert rel_err(scores4[t], want) <= REL
+    for k in (1, 2, 3):
+        have = d.score_all(k)
+        subs = oracle.enumerate_subsets(37, k)
+        for t in rng.choice(len(subs), size=6, replace=False):
+            ocnt = oracle.count(codes, card, subs[t])
+            want = [oracle.local_score(ocnt, card[subs[t]], ci) for ci in range(k)]
+            assert rel_err(have[t], want) <= REL
+    d.close()
