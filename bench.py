@@ -101,7 +101,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from openbnsl_amd import engine
+    from openbnsl_amd import distributed as obd, engine
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -126,7 +126,6 @@ def main():
               for k in range(1, mp + 2)]
     ptrs = [t.data_ptr() for t in tables]
     n_scores = sum(data.num_subsets(k) * k for k in range(1, mp + 2))
-    gathered = torch.empty((world, n, 3), dtype=torch.float64, device=dev) if world > 1 else None
 
     def step():
         data.pack()
@@ -134,13 +133,7 @@ def main():
             data.score_all_device(k, ptrs[k - 1], kind=kind, ess=1.0, shard=rank, num_shards=world)
         sc, sz, rk = data.best_parents(ptrs, mp)
         if world > 1:
-            mine = torch.from_numpy(np.stack([sc, sz.astype(np.float64), rk.astype(np.float64)], axis=1)).to(dev)
-            dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
-            g = gathered.cpu().numpy()
-            # best score, then fewer parents, then lower rank
-            order = np.lexsort((g[:, :, 2], g[:, :, 1], -g[:, :, 0]), axis=0)[0]
-            sel = g[order, np.arange(n)]
-            sc, sz, rk = sel[:, 0], sel[:, 1].astype(np.uint32), sel[:, 2].astype(np.uint64)
+            sc, sz, rk = obd.allgather_best(sc, sz, rk, device=dev)
         return sc, sz, rk
 
     for _ in range(args.warmup):

@@ -1,0 +1,105 @@
+"""GPU: the drop-in Python module, used the way the reference's own tests use
+`openbnsllib` (reference: pytest/base/test_contingency_table.py,
+pytest/score/test_local_score.py, pytest/structure_learning/test_exhaustive_search.py)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ob():
+    from openbnsl_amd import openbnsllib
+    assert openbnsllib.hip_enabled
+    return openbnsllib
+
+
+@pytest.mark.parametrize("frame", ["asia5k", "mixed3k", "lexi500"])
+def test_contingency_table_and_local_score(ob, golden, frame):
+    import pandas as pd
+    meta, arrays = golden
+    rec = meta[frame]
+    codes = arrays[frame + "_codes"]
+    df = pd.DataFrame({nm: np.array(rec["val_idx2str"][v], dtype=object)[codes[v]]
+                       for v, nm in enumerate(rec["columns"])})
+    w = ob.base.DataframeWrapper(df)
+    for tb in rec["tables"]:
+        vs = tb["var_ids"]
+        if len(vs) > 8:
+            continue
+        ct = ob.base.ContingencyTable(vs, w)
+        assert ct.var_ids == vs and ct.cardinalities == tb["cardinalities"]
+        assert {str(k): v for k, v in ct.counts.items()} == tb["counts"]
+        # reference: pytest/base/test_contingency_table.py:18-27
+        assert sum(ct.counts.values()) == w.num_of_datapoints
+        assert len(ct.counts) <= int(np.prod(tb["cardinalities"])) if vs else True
+        for ess, hexes in tb["scores"].items():
+            for ci, ch in enumerate(vs):
+                want = float.fromhex(hexes[ci])
+                have = ob.score.calculate_local_score(ch, [v for v in vs if v != ch], ct,
+                                                      ob.score.BDeu(float(ess)))
+                assert abs(have - want) <= 1e-9 * abs(want)
+                assert abs(have - want) < 1e-6          # the reference's own bar, test_local_score.py:57
+    ct = ob.base.ContingencyTable([0, 1], w)
+    with pytest.raises(ValueError, match="child_var not present in contingency table"):
+        ob.score.calculate_local_score(3, [0], ct, ob.score.BDeu(1.0))
+    for st in (ob.score.K2(), ob.score.AIC()):
+        with pytest.raises(ValueError, match="Unsupported score type"):
+            ob.score.calculate_local_score(0, [1], ct, st)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_local_score_random_parent_sets(ob, seed):
+    """Same protocol as pytest/score/test_local_score.py:20-57 (random child,
+    1..5 random parents, N = 1e5) on ALARM-shaped synthetic data; expectation
+    from the oracle instead of pgmpy."""
+    import oracle
+    from openbnsl_amd import synth
+    random.seed(seed)
+    codes, card, names = synth.alarm_shaped(100_000, seed=seed)
+    w = ob.base.DataframeWrapper(synth.to_dataframe(codes, names))
+    assert w.num_of_values == card.tolist()
+    n = w.num_of_vars
+    child = random.randint(0, n - 1)
+    cand = [i for i in range(n) if i != child]
+    parents = random.sample(cand, random.randint(1, 5))
+    vs = sorted(parents + [child])
+    ct = ob.base.ContingencyTable(vs, w)
+    have = ob.score.calculate_local_score(child, parents, ct, ob.score.BDeu(1.0))
+    want = oracle.local_score(oracle.count(codes, card, vs), card[vs], vs.index(child))
+    assert abs(have - want) < 1e-6
+    assert abs(have - want) <= 1e-9 * abs(want)
+
+
+def test_exhaustive_search_asia_recovers_structure(ob, golden):
+    """BASELINE config 1 (ASIA, 8 vars, 1e5 rows, BDeu): the same edge list the
+    reference returned on this data set, for max_parents 2 and 3."""
+    from openbnsl_amd import synth
+    meta, _ = golden
+    want = sorted(tuple(e) for e in meta["asia100k_full"]["exhaustive_search_edges"])
+    codes, card, names = synth.asia(100_000, seed=0)
+    w = ob.base.DataframeWrapper(synth.to_dataframe(codes, names, labels=[["no", "yes"]] * 8))
+    for mp in (2, 3):
+        g = ob.structure_learning.exhaustive_search(w, ob.score.BDeu(1.0), max_parents=mp)
+        have = sorted((names[j], names[v]) for v in range(8) for j in range(8) if g.has_edge(j, v))
+        assert have == want
+
+
+@pytest.mark.parametrize("cards,N,mp,kind", [
+    ([2, 3, 4, 2, 3, 2, 4, 3, 2, 3, 2, 4], 20_000, 3, "bdeu"),
+    ([2, 3, 2, 2, 3, 2, 2], 1_500, 2, "bic"),
+    ([2, 3, 2, 3, 2], 2_000, 4, "bdeu"),
+])
+def test_exhaustive_search_matches_oracle(ob, cards, N, mp, kind):
+    import oracle
+    from openbnsl_amd import synth
+    codes, card, names, _ = synth.random_bn(cards, N, seed=len(cards))
+    w = ob.base.DataframeWrapper(synth.to_dataframe(codes, names))
+    st = ob.score.BDeu(1.0) if kind == "bdeu" else ob.score.BIC()
+    g = ob.structure_learning.exhaustive_search(w, st, mp)
+    n = len(cards)
+    have = [[j for j in range(n) if g.has_edge(j, v)] for v in range(n)]
+    want, _ = oracle.exhaustive_search(codes, card, mp, oracle.BDEU if kind == "bdeu" else oracle.BIC)
+    assert have == want
