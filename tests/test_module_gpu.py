@@ -94,12 +94,26 @@ def test_exhaustive_search_asia_recovers_structure(ob, golden):
 ])
 def test_exhaustive_search_matches_oracle(ob, cards, N, mp, kind):
     import oracle
-    from openbnsl_amd import synth
+    from openbnsl_amd import graphs, synth
     codes, card, names, _ = synth.random_bn(cards, N, seed=len(cards))
     w = ob.base.DataframeWrapper(synth.to_dataframe(codes, names))
     st = ob.score.BDeu(1.0) if kind == "bdeu" else ob.score.BIC()
     g = ob.structure_learning.exhaustive_search(w, st, mp)
     n = len(cards)
-    have = [[j for j in range(n) if g.has_edge(j, v)] for v in range(n)]
-    want, _ = oracle.exhaustive_search(codes, card, mp, oracle.BDEU if kind == "bdeu" else oracle.BIC)
-    assert have == want
+    okind = oracle.BDEU if kind == "bdeu" else oracle.BIC
+    have = graphs.parent_lists(g)
+    want, want_total = oracle.exhaustive_search(codes, card, mp, okind)
+    # The emitted DAG is one member of the optimal Markov equivalence class; which
+    # member depends on last-bit differences between score-equivalent sets (the
+    # device lgamma is not glibc's), so compare what the reference's own test
+    # compares -- the equivalence class (SHD 0 between CPDAGs) -- plus optimality:
+    # the DAG's total score, evaluated by the oracle, equals the oracle's optimum.
+    assert graphs.is_acyclic(have)
+    assert all(len(ps) <= mp for ps in have)
+    total = 0.0
+    for v, ps in enumerate(have):
+        vs = sorted(ps + [v])
+        total += oracle.local_score(oracle.count(codes, card, vs), card[vs], vs.index(v), okind)
+    assert abs(total - want_total) <= 1e-9 * abs(want_total)
+    if kind == "bdeu":      # BDeu is score equivalent; BIC optima need not be unique classes
+        assert graphs.markov_equivalent(have, want)
