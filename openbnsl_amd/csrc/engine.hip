@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -139,8 +140,10 @@ __global__ __launch_bounds__(256) void bitgemm_kernel(
     uint32_t nrows, const ColDesc* __restrict__ cols, uint32_t ncols_total,
     const uint2* __restrict__ items, uint32_t nitems, uint32_t* __restrict__ counts,
     uint32_t steps_total, uint32_t steps_per_split, int use_atomics) {
-  __shared__ __attribute__((aligned(16))) uint32_t sA[BM * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint32_t sB[BN * LDS_STRIDE];
+  // two slabs of A and of B: slab (s & 1) is read while slab ((s + 1) & 1) is
+  // filled, one barrier per step.  One array (a second __shared__ object beside
+  // it could make the compiler drain loads before every LDS read).
+  __shared__ __attribute__((aligned(16))) uint32_t smem[2 * (BM + BN) * LDS_STRIDE];
 
   const uint32_t item_id = blockIdx.x % nitems;
   const uint32_t split = blockIdx.x / nitems;
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(256) void bitgemm_kernel(
 #pragma unroll
     for (int j = 0; j < KC; ++j) boff[p][j] = cols[c].plane[j] * wp + q * 4;
   }
+  const uint32_t st_off = rl * LDS_STRIDE + q * 4;  // this thread's uint4 in a slab (row rl)
 
   const uint32_t tn = tid & 15, tm = tid >> 4;
   uint32_t acc[8][8];
@@ -170,22 +174,46 @@ __global__ __launch_bounds__(256) void bitgemm_kernel(
 
   const uint32_t step_lo = split * steps_per_split;
   const uint32_t step_hi = min(step_lo + steps_per_split, steps_total);
-  for (uint32_t step = step_lo; step < step_hi; ++step) {
+  uint4 ga[4][KR], gb[4][KC];  // raw plane words of the next slab, in flight during compute
+
+  auto issue_loads = [&](uint32_t step) {
     const uint32_t w0 = step * KCW;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      uint4 va = *reinterpret_cast<const uint4*>(planes + aoff[p][0] + w0);
 #pragma unroll
-      for (int j = 1; j < KR; ++j)
-        va = and4(va, *reinterpret_cast<const uint4*>(planes + aoff[p][j] + w0));
-      uint4 vb = *reinterpret_cast<const uint4*>(planes + boff[p][0] + w0);
+      for (int j = 0; j < KR; ++j)
+        ga[p][j] = *reinterpret_cast<const uint4*>(planes + aoff[p][j] + w0);
 #pragma unroll
-      for (int j = 1; j < KC; ++j)
-        vb = and4(vb, *reinterpret_cast<const uint4*>(planes + boff[p][j] + w0));
-      *reinterpret_cast<uint4*>(&sA[(rl + 32 * p) * LDS_STRIDE + q * 4]) = va;
-      *reinterpret_cast<uint4*>(&sB[(rl + 32 * p) * LDS_STRIDE + q * 4]) = vb;
+      for (int j = 0; j < KC; ++j)
+        gb[p][j] = *reinterpret_cast<const uint4*>(planes + boff[p][j] + w0);
     }
-    __syncthreads();
+  };
+  auto write_slab = [&](uint32_t buf) {
+    uint32_t* sA = smem + buf * (BM + BN) * LDS_STRIDE;
+    uint32_t* sB = sA + BM * LDS_STRIDE;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      uint4 va = ga[p][0], vb = gb[p][0];
+#pragma unroll
+      for (int j = 1; j < KR; ++j) va = and4(va, ga[p][j]);
+#pragma unroll
+      for (int j = 1; j < KC; ++j) vb = and4(vb, gb[p][j]);
+      *reinterpret_cast<uint4*>(&sA[st_off + 32 * p * LDS_STRIDE]) = va;
+      *reinterpret_cast<uint4*>(&sB[st_off + 32 * p * LDS_STRIDE]) = vb;
+    }
+  };
+
+  if (step_lo < step_hi) {
+    issue_loads(step_lo);
+    write_slab(0);
+  }
+  __syncthreads();
+  for (uint32_t step = step_lo; step < step_hi; ++step) {
+    const uint32_t buf = (step - step_lo) & 1;
+    const bool more = step + 1 < step_hi;
+    if (more) issue_loads(step + 1);
+    const uint32_t* sA = smem + buf * (BM + BN) * LDS_STRIDE;
+    const uint32_t* sB = sA + BM * LDS_STRIDE;
 #pragma unroll 1
     for (int kq = 0; kq < KCW / 4; ++kq) {
       uint4 a[8], b[8];
@@ -205,6 +233,7 @@ __global__ __launch_bounds__(256) void bitgemm_kernel(
           acc[i][j] += __popc(a[i].w & b[j].w);
         }
     }
+    if (more) write_slab(buf ^ 1);
     __syncthreads();
   }
 
@@ -972,9 +1001,15 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
     if (b->nitems == 0 || b->ntables == 0) continue;
     HIP_TRY(d->counts.ensure(b->ncells));
     // split the contraction when there are too few tiles to fill the chip
+    // (workgroups of equal length run in rounds of 2 per CU; many short ones keep
+    // the last round from idling most of the chip)
     uint32_t ksplit = 1;
-    const uint32_t want = 256 * 8;
-    if (b->nitems < want) ksplit = std::min<uint32_t>((want + b->nitems - 1) / b->nitems, steps_total);
+    static const uint32_t want = [] {
+      const char* e = std::getenv("OBNSL_TARGET_WGS");
+      return e ? (uint32_t)std::atoi(e) : 8192u;
+    }();
+    const uint32_t max_split = std::max<uint32_t>(1, steps_total / 8);
+    if (b->nitems < want) ksplit = std::min<uint32_t>((want + b->nitems - 1) / b->nitems, max_split);
     const uint32_t sps = (steps_total + ksplit - 1) / ksplit;
     ksplit = (steps_total + sps - 1) / sps;
     const int atomics = ksplit > 1;
