@@ -47,6 +47,7 @@ constexpr int BM = 128, BN = 128;       // C tile of one workgroup
 constexpr int KCW = 32;                 // 32-bit words of the contraction per LDS slab
 constexpr int LDS_STRIDE = KCW + 4;     // padded slab row (words): conflict-free b128 reads
 constexpr uint64_t BATCH_CELL_CAP = 1ull << 30;  // counters per batch (4 GiB)
+constexpr uint64_t REDUCED_MAX_CELLS = 4096;     // largest full table the reduced-mode scorer expands in LDS
 
 thread_local std::string g_err;
 
@@ -394,6 +395,112 @@ __global__ __launch_bounds__(256) void score_tables_kernel(
   score_table(counts + td.off, td.k, cards, kind, ess, lane, scores + t * td.k);
 }
 
+// ---- reduced ("non-reference states only") tables -> full tables -> scores
+//
+// In reduced mode the bit-GEMM counts, for every subset T, only the joint states
+// in which every variable of T is in one of its states 1..r-1:
+//   R_T(y) = #{rows : x_v = y_v for all v in T},  y_v >= 1.
+// That is prod(r_v - 1) cells instead of prod(r_v).  The full table of a subset S
+// follows from the reduced tables of all T subset-of S: write "any" for digit 0,
+//   E_S(e) = R_supp(e)(e restricted to its non-zero digits),   E_S(all any) = N,
+// then turn "any" into "state 0" one variable at a time,
+//   F(.., 0, ..) = E(.., any, ..) - sum_{s>=1} E(.., s, ..),
+// which is exact integer arithmetic (inclusion-exclusion).
+struct SizeView {            // where the reduced tables of one subset size live
+  const uint32_t* red;       // counters
+  const uint64_t* rowoff;    // first counter of a row group, by colex rank of its kr-subset
+  const ColGroupDesc* cgs;   // column groups in colex order (col_before in reduced cells)
+  uint32_t kr, kc;
+};
+struct ReducedViews {
+  SizeView v[KMAX + 1];
+};
+
+// One wavefront (one 64-thread workgroup) per table: gather E from the reduced
+// tables of the 2^k - 1 non-empty sub-subsets, k in-place passes, then the k scores.
+__global__ __launch_bounds__(64) void score_reduced_kernel(
+    ReducedViews views, const RowGroupDesc* __restrict__ rgs, uint32_t nrgs, uint32_t k,
+    uint64_t ntables, const uint32_t* __restrict__ card, const uint64_t* __restrict__ binom,
+    uint32_t num_rows, int kind, double ess, double* __restrict__ scores) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t E[];
+  __shared__ SizeView sv[KMAX + 1];
+  const uint32_t lane = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j <= KMAX; ++j)
+    if (lane == (uint32_t)j) sv[j] = views.v[j];
+  const uint64_t t = blockIdx.x;
+  uint32_t lo = 0, hi = nrgs - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (rgs[mid].tbl_start <= t) lo = mid;
+    else hi = mid - 1;
+  }
+  const RowGroupDesc rg = rgs[lo];
+  const uint32_t gamma = (uint32_t)(t - rg.tbl_start);
+  const uint32_t kc = k / 2, kr = k - kc;
+  uint32_t vars[KMAX], cards[KMAX];
+  __syncthreads();
+  if (kc > 0) {
+    const ColGroupDesc cg = sv[k].cgs[gamma];
+    for (uint32_t j = 0; j < kc; ++j) vars[j] = cg.vars[j];
+  }
+  for (uint32_t j = 0; j < kr; ++j) vars[kc + j] = rg.vars[j];
+  uint32_t cells = 1;
+  for (uint32_t i = 0; i < k; ++i) {
+    cards[i] = card[vars[i]];
+    cells *= cards[i];
+  }
+
+  for (uint32_t cell = lane; cell < cells; cell += 64) {
+    uint32_t e[KMAX];
+    uint32_t rem = cell, nz = 0;
+    for (int i = (int)k - 1; i >= 0; --i) {
+      e[i] = rem % cards[i];
+      rem /= cards[i];
+      nz += e[i] != 0;
+    }
+    uint32_t val = num_rows;
+    if (nz) {
+      const SizeView s = sv[nz];
+      uint64_t colrank = 0, rowrank = 0;
+      uint32_t keycol = 0, keyrow = 0, mred = 1, p = 0;
+      for (uint32_t i = 0; i < k; ++i) {
+        if (e[i] == 0) continue;
+        ++p;
+        const uint32_t rad = cards[i] - 1;
+        if (p <= s.kc) {
+          colrank += binom[vars[i] * (KMAX + 1) + p];
+          keycol = keycol * rad + (e[i] - 1);
+        } else {
+          rowrank += binom[vars[i] * (KMAX + 1) + (p - s.kc)];
+          keyrow = keyrow * rad + (e[i] - 1);
+          mred *= rad;
+        }
+      }
+      const uint32_t col_before = s.kc ? s.cgs[colrank].col_before : 0;
+      val = s.red[s.rowoff[rowrank] + (uint64_t)(col_before + keycol) * mred + keyrow];
+    }
+    E[cell] = val;
+  }
+  __syncthreads();
+  uint32_t w = 1;
+  for (int i = (int)k - 1; i >= 0; --i) {
+    const uint32_t r = cards[i];
+    const uint32_t lines = cells / r;
+    for (uint32_t l = lane; l < lines; l += 64) {
+      const uint32_t h = l / w, lo_ = l - h * w;
+      const uint32_t base = h * (r * w) + lo_;
+      uint32_t s = 0;
+      for (uint32_t st = 1; st < r; ++st) s += E[base + st * w];
+      E[base] -= s;
+    }
+    __syncthreads();
+    w *= r;
+  }
+  const uint64_t rank = rg.rank_part + gamma;
+  score_table(E, k, cards, kind, ess, lane, scores + rank * k);
+}
+
 // ------------------------------------------------------------------ best parents
 __device__ __forceinline__ uint64_t ordered_key(double x) {
   const uint64_t b = (uint64_t)__double_as_longlong(x);
@@ -498,10 +605,16 @@ struct Batch {
 
 struct Plan {
   uint32_t k = 0, kr = 0, kc = 0;
+  bool reduced = false;         // rows/columns cover states 1..r-1 only (see score_reduced_kernel)
   DevBuf<ColDesc> cols;
   DevBuf<ColGroupDesc> cgs;
   uint32_t ncols_total = 0;
-  std::vector<std::unique_ptr<Batch>> batches;
+  std::vector<std::unique_ptr<Batch>> batches;  // exactly one in reduced mode
+  // reduced mode: the counters persist per plan, so that larger subsets can read them
+  DevBuf<uint32_t> red;
+  DevBuf<uint64_t> rowoff;      // by colex rank of the kr-subset
+  uint64_t counted_epoch = 0;   // data epoch the counters in `red` belong to
+  uint64_t total_items = 0;
 };
 
 }  // namespace
@@ -515,9 +628,11 @@ struct obnsl_data {
   DevBuf<uint8_t> codes;
   DevBuf<uint32_t> planes, d_card, d_plane_base, counts;
   DevBuf<uint64_t> d_binom;
-  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::unique_ptr<Plan>> plans;
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t, bool>, std::unique_ptr<Plan>> plans;
+  uint64_t epoch = 1;                                 // bumped whenever the planes are rebuilt
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // around each bit-GEMM launch
-  uint32_t ev_used = 0, ev_k = 0;                     // pending pairs and their subset size
+  std::vector<uint32_t> ev_size;                      // subset size of each pending pair
+  uint32_t ev_used = 0;                               // pending pairs
   double acc_ms[OBNSL_MAX_SUBSET + 1] = {0};          // per subset size, since the last reset
   uint32_t acc_launches[OBNSL_MAX_SUBSET + 1] = {0};
   ~obnsl_data() {
@@ -554,8 +669,8 @@ void enumerate_colex(uint32_t n, uint32_t k, std::vector<std::vector<uint32_t>>&
 }
 
 obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nshards,
-                        Plan** out) {
-  auto key = std::make_tuple(k, shard, nshards);
+                        bool reduced, Plan** out) {
+  auto key = std::make_tuple(k, shard, nshards, reduced);
   auto itp = d->plans.find(key);
   if (itp != d->plans.end()) {
     *out = itp->second.get();
@@ -565,7 +680,11 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
   plan->k = k;
   plan->kc = k / 2;
   plan->kr = k - plan->kc;
+  plan->reduced = reduced;
   const uint32_t kr = plan->kr, kc = plan->kc, n = d->n;
+  // states a row/column enumerates per variable, and the plane of the first one
+  auto radix = [&](uint32_t v) { return reduced ? d->card[v] - 1 : d->card[v]; };
+  const uint32_t first_state = reduced ? 1 : 0;
 
   // column side: every kc-subset in colex order, cells with the first variable
   // most significant
@@ -577,7 +696,7 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     uint64_t total = 0;
     for (size_t g = 0; g < csub.size(); ++g) {
       uint64_t cells = 1;
-      for (uint32_t v : csub[g]) cells *= d->card[v];
+      for (uint32_t v : csub[g]) cells *= radix(v);
       total += cells;
       if (total > (1u << 27))
         return fail(OBNSL_ERR_UNSUPPORTED, "column side of the table batch is too large");
@@ -590,7 +709,7 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
       uint32_t cells = 1;
       for (uint32_t j = 0; j < kc; ++j) {
         cg.vars[j] = csub[g][j];
-        cells *= d->card[csub[g][j]];
+        cells *= radix(csub[g][j]);
       }
       cg.col_before = before;
       cg.cells = cells;
@@ -599,14 +718,19 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
         for (int j = 0; j < KSIDE; ++j) cd.plane[j] = d->ones_plane;
         uint32_t rem = cell;
         for (int j = (int)kc - 1; j >= 0; --j) {
-          const uint32_t r = d->card[csub[g][j]];
-          cd.plane[j] = d->plane_base[csub[g][j]] + rem % r;
+          const uint32_t r = radix(csub[g][j]);
+          cd.plane[j] = d->plane_base[csub[g][j]] + first_state + rem % r;
           rem /= r;
         }
         cols.push_back(cd);
       }
       before += cells;
     }
+  }
+  if (cols.empty()) {  // keeps the kernel's clamped column index valid; never a valid column
+    ColDesc cd;
+    for (int j = 0; j < KSIDE; ++j) cd.plane[j] = d->ones_plane;
+    cols.push_back(cd);
   }
   plan->ncols_total = (uint32_t)cols.size();
   // columns usable by a row group whose smallest variable is u: those of the
@@ -615,7 +739,7 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
   for (uint32_t u = 0; u <= n; ++u) {
     const uint64_t g = kc == 0 ? 1 : binom_host(u, kc);
     if (g == 0) ncols_below[u] = 0;
-    else if (g >= cgs.size()) ncols_below[u] = (uint32_t)cols.size();
+    else if (g >= cgs.size()) ncols_below[u] = cgs.back().col_before + cgs.back().cells;
     else ncols_below[u] = cgs[g].col_before;
   }
 
@@ -633,7 +757,7 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
   std::vector<uint64_t> Ms(rsub.size());
   for (size_t g = 0; g < rsub.size(); ++g) {
     uint64_t M = 1;
-    for (uint32_t v : rsub[g]) M *= d->card[v];
+    for (uint32_t v : rsub[g]) M *= radix(v);
     if (M > (1u << 24)) return fail(OBNSL_ERR_UNSUPPORTED, "row side of a table is too large");
     Ms[g] = M;
     cum[g + 1] = cum[g] + M * ncols_below[rsub[g][0]];
@@ -650,8 +774,11 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     if (shard == 0) g_lo = 0;
   }
 
+  std::vector<uint64_t> rowoff;
+  if (reduced) rowoff.assign(binom_host(n, kr), 0);
+  const uint64_t cell_cap = reduced ? (1ull << 33) : BATCH_CELL_CAP;
   size_t g = g_lo;
-  while (g < g_hi) {
+  while (g < g_hi || (reduced && plan->batches.empty())) {
     auto b = std::make_unique<Batch>();
     std::vector<RowDesc> rows;
     std::vector<RowGroupDesc> rgs;
@@ -660,16 +787,21 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
       const uint64_t M = Ms[g];
       const uint32_t u1 = rsub[g][0];
       const uint64_t sz = M * ncols_below[u1];
-      if (off > 0 && off + sz > BATCH_CELL_CAP) break;
+      if (off > 0 && off + sz > cell_cap) {
+        if (reduced) return fail(OBNSL_ERR_UNSUPPORTED, "reduced count tables exceed 2^33 cells");
+        break;
+      }
       if (rows.size() + M > (1u << 27))
         return fail(OBNSL_ERR_UNSUPPORTED, "row side of the table batch is too large");
       RowGroupDesc rg;
       std::memset(&rg, 0, sizeof(rg));
-      uint64_t rank_part = 0;
+      uint64_t rank_part = 0, own_rank = 0;
       for (uint32_t j = 0; j < kr; ++j) {
         rg.vars[j] = rsub[g][j];
         rank_part += binom_host(rsub[g][j], kc + j + 1);
+        own_rank += binom_host(rsub[g][j], j + 1);
       }
+      if (reduced) rowoff[own_rank] = off;
       rg.out_off = off;
       rg.rank_part = rank_part;
       rg.tbl_start = tables;
@@ -681,8 +813,8 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
         for (int j = 0; j < KSIDE; ++j) rd.plane[j] = d->ones_plane;
         uint32_t rem = cell;
         for (int j = (int)kr - 1; j >= 0; --j) {
-          const uint32_t r = d->card[rsub[g][j]];
-          rd.plane[j] = d->plane_base[rsub[g][j]] + rem % r;
+          const uint32_t r = radix(rsub[g][j]);
+          rd.plane[j] = d->plane_base[rsub[g][j]] + first_state + rem % r;
           rem /= r;
         }
         rd.out_base = off + cell;
@@ -717,7 +849,12 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     HIP_TRY(b->rows.upload(rows));
     HIP_TRY(b->items.upload(items));
     HIP_TRY(b->rgs.upload(rgs));
+    plan->total_items += b->nitems;
     plan->batches.push_back(std::move(b));
+  }
+  if (reduced) {
+    HIP_TRY(plan->rowoff.upload(rowoff));
+    HIP_TRY(plan->red.ensure(std::max<uint64_t>(plan->batches[0]->ncells, 1)));
   }
   HIP_TRY(plan->cols.upload(cols));
   HIP_TRY(plan->cgs.upload(cgs));
@@ -733,19 +870,73 @@ obnsl_status resolve_events(obnsl_data* d) {
     float t = 0;
     HIP_TRY(hipEventSynchronize(d->ev[i].second));
     HIP_TRY(hipEventElapsedTime(&t, d->ev[i].first, d->ev[i].second));
-    d->acc_ms[d->ev_k] += t;
-    d->acc_launches[d->ev_k] += 1;
+    d->acc_ms[d->ev_size[i]] += t;
+    d->acc_launches[d->ev_size[i]] += 1;
   }
   d->ev_used = 0;
   return OBNSL_OK;
 }
 
 template <int KR, int KC>
-void launch_bitgemm(obnsl_data* d, const Plan* p, const Batch* b, uint32_t grid,
+void launch_bitgemm(obnsl_data* d, const Plan* p, const Batch* b, uint32_t* counts, uint32_t grid,
                     uint32_t steps_total, uint32_t steps_per_split, int atomics) {
   hipLaunchKernelGGL((bitgemm_kernel<KR, KC>), dim3(grid), dim3(256), 0, d->stream,
                      d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
-                     b->items.p, b->nitems, d->counts.p, steps_total, steps_per_split, atomics);
+                     b->items.p, b->nitems, counts, steps_total, steps_per_split, atomics);
+}
+
+// One bit-GEMM launch (timed with an event pair) filling `counts` for one batch.
+obnsl_status launch_count(obnsl_data* d, const Plan* plan, const Batch* b, uint32_t* counts) {
+  if (b->nitems == 0) return OBNSL_OK;
+  const uint32_t steps_total = d->wp / KCW;
+  // split the contraction when there are too few tiles to fill the chip
+  // (workgroups of equal length run in rounds of 2 per CU; many short ones keep
+  // the last round from idling most of the chip)
+  uint32_t ksplit = 1;
+  static const uint32_t want = [] {
+    const char* e = std::getenv("OBNSL_TARGET_WGS");
+    return e ? (uint32_t)std::atoi(e) : 8192u;
+  }();
+  const uint32_t max_split = std::max<uint32_t>(1, steps_total / 8);
+  if (b->nitems < want) ksplit = std::min<uint32_t>((want + b->nitems - 1) / b->nitems, max_split);
+  const uint32_t sps = (steps_total + ksplit - 1) / ksplit;
+  ksplit = (steps_total + sps - 1) / sps;
+  const int atomics = ksplit > 1;
+  if (atomics) HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->stream));
+  if (d->ev_used == d->ev.size()) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    d->ev.push_back({e0, e1});
+    d->ev_size.push_back(0);
+  }
+  d->ev_size[d->ev_used] = plan->k;
+  auto& ev = d->ev[d->ev_used++];
+  HIP_TRY(hipEventRecord(ev.first, d->stream));
+  const uint32_t grid = b->nitems * ksplit;
+  const uint32_t kcn = plan->kc == 0 ? 1 : plan->kc;  // kc == 0: the single ONES column
+  switch (plan->kr * 10 + kcn) {
+    case 11: launch_bitgemm<1, 1>(d, plan, b, counts, grid, steps_total, sps, atomics); break;
+    case 21: launch_bitgemm<2, 1>(d, plan, b, counts, grid, steps_total, sps, atomics); break;
+    case 22: launch_bitgemm<2, 2>(d, plan, b, counts, grid, steps_total, sps, atomics); break;
+    case 32: launch_bitgemm<3, 2>(d, plan, b, counts, grid, steps_total, sps, atomics); break;
+    case 33: launch_bitgemm<3, 3>(d, plan, b, counts, grid, steps_total, sps, atomics); break;
+    case 43: launch_bitgemm<4, 3>(d, plan, b, counts, grid, steps_total, sps, atomics); break;
+    case 44: launch_bitgemm<4, 4>(d, plan, b, counts, grid, steps_total, sps, atomics); break;
+    default: return fail(OBNSL_ERR_RUNTIME, "internal: no bit-GEMM instance");
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev.second, d->stream));
+  return OBNSL_OK;
+}
+
+// Reduced mode: make plan->red hold the counts of the current planes.
+obnsl_status ensure_counts(obnsl_data* d, Plan* plan) {
+  if (plan->counted_epoch == d->epoch) return OBNSL_OK;
+  obnsl_status st = launch_count(d, plan, plan->batches[0].get(), plan->red.p);
+  if (st != OBNSL_OK) return st;
+  plan->counted_epoch = d->epoch;
+  return OBNSL_OK;
 }
 
 obnsl_status check_kind(obnsl_score_kind kind) {
@@ -764,6 +955,7 @@ obnsl_status run_pack(obnsl_data* d) {
                      d->stride, d->n, d->d_card.p, d->d_plane_base.p, d->planes.p, d->wp,
                      d->ones_plane);
   HIP_TRY(hipGetLastError());
+  d->epoch++;  // every cached count table is stale now
   return OBNSL_OK;
 }
 
@@ -981,10 +1173,6 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
   if (st != OBNSL_OK) return st;
   st = set_device(d->device);
   if (st != OBNSL_OK) return st;
-  Plan* plan = nullptr;
-  st = build_plan(d, k, shard, num_shards, &plan);
-  if (st != OBNSL_OK) return st;
-
   const uint64_t nsub = binom_host(d->n, k);
   DevBuf<double> tmp;
   double* d_scores = scores_out;
@@ -994,53 +1182,69 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
   }
   st = resolve_events(d);
   if (st != OBNSL_OK) return st;
-  d->ev_k = k;
-  const uint32_t steps_total = d->wp / KCW;
-  for (auto& bp : plan->batches) {
-    Batch* b = bp.get();
-    if (b->nitems == 0 || b->ntables == 0) continue;
-    HIP_TRY(d->counts.ensure(b->ncells));
-    // split the contraction when there are too few tiles to fill the chip
-    // (workgroups of equal length run in rounds of 2 per CU; many short ones keep
-    // the last round from idling most of the chip)
-    uint32_t ksplit = 1;
-    static const uint32_t want = [] {
-      const char* e = std::getenv("OBNSL_TARGET_WGS");
-      return e ? (uint32_t)std::atoi(e) : 8192u;
-    }();
-    const uint32_t max_split = std::max<uint32_t>(1, steps_total / 8);
-    if (b->nitems < want) ksplit = std::min<uint32_t>((want + b->nitems - 1) / b->nitems, max_split);
-    const uint32_t sps = (steps_total + ksplit - 1) / ksplit;
-    ksplit = (steps_total + sps - 1) / sps;
-    const int atomics = ksplit > 1;
-    if (atomics) HIP_TRY(hipMemsetAsync(d->counts.p, 0, b->ncells * sizeof(uint32_t), d->stream));
-    if (d->ev_used == d->ev.size()) {
-      hipEvent_t e0, e1;
-      HIP_TRY(hipEventCreate(&e0));
-      HIP_TRY(hipEventCreate(&e1));
-      d->ev.push_back({e0, e1});
+
+  // Reduced mode (count only states 1..r-1, expand in the scorer) whenever the
+  // largest full table of this size fits the scorer's LDS; otherwise every state
+  // is counted directly.
+  std::vector<uint32_t> sorted_card(d->card);
+  std::sort(sorted_card.rbegin(), sorted_card.rend());
+  uint64_t max_cells = 1;
+  for (uint32_t i = 0; i < k; ++i) max_cells *= sorted_card[i];
+  static const bool allow_reduced = std::getenv("OBNSL_NO_REDUCED") == nullptr;
+  if (allow_reduced && max_cells <= REDUCED_MAX_CELLS) {
+    ReducedViews views;
+    std::memset(&views, 0, sizeof(views));
+    Plan* own = nullptr;     // lists this shard's tables
+    for (uint32_t j = 1; j <= k; ++j) {
+      Plan* full = nullptr;
+      Plan* use = nullptr;
+      if (j < k || num_shards == 1) {
+        st = build_plan(d, j, 0, 1, true, &full);
+        if (st != OBNSL_OK) return st;
+        use = full;
+      }
+      if (j == k) {
+        st = build_plan(d, k, shard, num_shards, true, &own);
+        if (st != OBNSL_OK) return st;
+        if (num_shards > 1) {
+          // a small top size is cheaper to count whole than to count twice
+          st = build_plan(d, k, 0, 1, true, &full);
+          if (st != OBNSL_OK) return st;
+          use = (full->total_items <= 64 || full->counted_epoch == d->epoch) ? full : own;
+        }
+      }
+      st = ensure_counts(d, use);
+      if (st != OBNSL_OK) return st;
+      views.v[j].red = use->red.p;
+      views.v[j].rowoff = use->rowoff.p;
+      views.v[j].cgs = use->cgs.p;
+      views.v[j].kr = use->kr;
+      views.v[j].kc = use->kc;
     }
-    auto& ev = d->ev[d->ev_used++];
-    HIP_TRY(hipEventRecord(ev.first, d->stream));
-    const uint32_t grid = b->nitems * ksplit;
-    const uint32_t kcn = plan->kc == 0 ? 1 : plan->kc;  // kc == 0: the single ONES column
-    switch (plan->kr * 10 + kcn) {
-      case 11: launch_bitgemm<1, 1>(d, plan, b, grid, steps_total, sps, atomics); break;
-      case 21: launch_bitgemm<2, 1>(d, plan, b, grid, steps_total, sps, atomics); break;
-      case 22: launch_bitgemm<2, 2>(d, plan, b, grid, steps_total, sps, atomics); break;
-      case 32: launch_bitgemm<3, 2>(d, plan, b, grid, steps_total, sps, atomics); break;
-      case 33: launch_bitgemm<3, 3>(d, plan, b, grid, steps_total, sps, atomics); break;
-      case 43: launch_bitgemm<4, 3>(d, plan, b, grid, steps_total, sps, atomics); break;
-      case 44: launch_bitgemm<4, 4>(d, plan, b, grid, steps_total, sps, atomics); break;
-      default: return fail(OBNSL_ERR_RUNTIME, "internal: no bit-GEMM instance");
+    const Batch* b = own->batches[0].get();
+    if (b->ntables) {
+      hipLaunchKernelGGL(score_reduced_kernel, dim3((uint32_t)b->ntables), dim3(64),
+                         (size_t)max_cells * sizeof(uint32_t), d->stream, views, b->rgs.p, b->nrgs,
+                         k, b->ntables, d->d_card.p, d->d_binom.p, (uint32_t)d->N, (int)kind, ess,
+                         d_scores);
+      HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev.second, d->stream));
-    const uint32_t sgrid = (uint32_t)((b->ntables + 3) / 4);
-    hipLaunchKernelGGL(score_plan_kernel, dim3(sgrid), dim3(256), 0, d->stream, d->counts.p,
-                       b->rgs.p, b->nrgs, plan->cgs.p, d->d_card.p, plan->kr, plan->kc,
-                       b->ntables, (int)kind, ess, d_scores);
-    HIP_TRY(hipGetLastError());
+  } else {
+    Plan* plan = nullptr;
+    st = build_plan(d, k, shard, num_shards, false, &plan);
+    if (st != OBNSL_OK) return st;
+    for (auto& bp : plan->batches) {
+      Batch* b = bp.get();
+      if (b->ntables == 0) continue;
+      HIP_TRY(d->counts.ensure(std::max<uint64_t>(b->ncells, 1)));
+      st = launch_count(d, plan, b, d->counts.p);
+      if (st != OBNSL_OK) return st;
+      const uint32_t sgrid = (uint32_t)((b->ntables + 3) / 4);
+      hipLaunchKernelGGL(score_plan_kernel, dim3(sgrid), dim3(256), 0, d->stream, d->counts.p,
+                         b->rgs.p, b->nrgs, plan->cgs.p, d->d_card.p, plan->kr, plan->kc,
+                         b->ntables, (int)kind, ess, d_scores);
+      HIP_TRY(hipGetLastError());
+    }
   }
   if (!out_on_device) {
     HIP_TRY(hipMemcpyAsync(scores_out, d_scores, nsub * k * sizeof(double), hipMemcpyDeviceToHost, d->stream));
