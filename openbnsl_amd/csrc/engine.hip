@@ -418,12 +418,25 @@ struct ReducedViews {
 
 // One wavefront (one 64-thread workgroup) per table: gather E from the reduced
 // tables of the 2^k - 1 non-empty sub-subsets, k in-place passes, then the k scores.
+//
+// Scores come from a per-table functional: with
+//   G(T) = sum over non-zero cells c of T of [lgamma(N_c + ess/cells(T)) - lgamma(ess/cells(T))]
+// the reference's BDeu local score (include/score/local_score.h:38-61) is
+//   score(v | P) = G(P + v) - G(P),
+// because the parent-configuration counts N_ij of the table over P + v are the
+// cells of the table over P, and alpha_ij = alpha_ijk * r_v = ess / cells(P).
+// (BIC: the same with G(T) = sum N_c ln N_c, minus the penalty.)  So this kernel
+// evaluates ONE sum per table, stores it in G[rank], and lane i < k writes
+// score i = G(S) - Gprev[rank(S without v_i)]; Gprev belongs to the next smaller
+// subset size (g0 for the empty set).  scores may be null (G only).
 __global__ __launch_bounds__(64) void score_reduced_kernel(
     ReducedViews views, const RowGroupDesc* __restrict__ rgs, uint32_t nrgs, uint32_t k,
     uint64_t ntables, const uint32_t* __restrict__ card, const uint64_t* __restrict__ binom,
-    uint32_t num_rows, int kind, double ess, double* __restrict__ scores) {
+    uint32_t num_rows, int kind, double ess, double* __restrict__ G,
+    const double* __restrict__ Gprev, double g0, double* __restrict__ scores) {
   extern __shared__ __attribute__((aligned(16))) uint32_t E[];
   __shared__ SizeView sv[KMAX + 1];
+  __shared__ uint32_t s_vars[KMAX], s_cards[KMAX];
   const uint32_t lane = threadIdx.x;
 #pragma unroll
   for (int j = 0; j <= KMAX; ++j)
@@ -498,7 +511,48 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
     w *= r;
   }
   const uint64_t rank = rg.rank_part + gamma;
-  score_table(E, k, cards, kind, ess, lane, scores + rank * k);
+  double g = 0.0;
+  if (kind == OBNSL_SCORE_BDEU) {
+    const double a = ess / (double)cells;
+    const double lg_a = lgamma(a);
+    for (uint32_t c = lane; c < cells; c += 64) {
+      const uint32_t nc = E[c];
+      if (nc) g += lgamma((double)nc + a) - lg_a;
+    }
+  } else {
+    for (uint32_t c = lane; c < cells; c += 64) {
+      const uint32_t nc = E[c];
+      if (nc) g += (double)nc * log((double)nc);
+    }
+  }
+  g = wave_sum(g);
+  if (lane == 0) G[rank] = g;
+  if (scores == nullptr) return;
+  for (uint32_t i = 0; i < k; ++i)
+    if (lane == i) {
+      s_vars[i] = vars[i];
+      s_cards[i] = cards[i];
+    }
+  __syncthreads();
+  if (lane < k) {
+    double gp = g0;
+    if (k > 1) {
+      uint64_t sub = 0;
+      uint32_t pos = 1;
+      for (uint32_t j = 0; j < k; ++j) {
+        if (j == lane) continue;
+        sub += binom[s_vars[j] * (KMAX + 1) + pos];
+        ++pos;
+      }
+      gp = Gprev[sub];
+    }
+    double sc = g - gp;
+    if (kind == OBNSL_SCORE_BIC) {
+      const uint32_t r = s_cards[lane];
+      sc -= 0.5 * log((double)num_rows) * (double)(cells / r) * (double)(r - 1);
+    }
+    scores[rank * k + lane] = sc;
+  }
 }
 
 // ------------------------------------------------------------------ best parents
@@ -521,35 +575,60 @@ __device__ __forceinline__ uint32_t unrank_step(const uint64_t* __restrict__ bin
 
 // pass 0: best_key[v] = max ordered score; pass 1: best_id[v] = min id among
 // the entries that reach it, id = (parents << 56) | colex rank of the parent set.
+// Every score of a table competes for one of only n addresses, so each
+// workgroup first reduces its share in LDS (n <= BEST_LDS_VARS) and then issues
+// at most n global atomics.
+constexpr uint32_t BEST_LDS_VARS = 2048;
 __global__ __launch_bounds__(256) void best_parents_kernel(
     const double* __restrict__ scores, uint64_t nsubsets, uint32_t k, uint32_t n,
     const uint64_t* __restrict__ binom, unsigned long long* __restrict__ best_key,
     unsigned long long* __restrict__ best_id, int pass) {
-  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= nsubsets) return;
-  uint32_t vars[KMAX];
-  uint64_t rem = t;
-  for (uint32_t j = k; j >= 1; --j) {
-    const uint32_t v = unrank_step(binom, n, j, rem);
-    vars[j - 1] = v;
-    rem -= binom[v * (KMAX + 1) + j];
+  __shared__ unsigned long long s_best[BEST_LDS_VARS];
+  const bool use_lds = n <= BEST_LDS_VARS;
+  if (use_lds) {
+    for (uint32_t v = threadIdx.x; v < n; v += 256) s_best[v] = pass == 0 ? 0ull : ~0ull;
+    __syncthreads();
   }
-  for (uint32_t i = 0; i < k; ++i) {
-    const double sc = scores[t * k + i];
-    if (!(sc > -INFINITY)) continue;  // -inf fill (other shard) or NaN
-    const unsigned long long key = ordered_key(sc);
-    const uint32_t v = vars[i];
-    if (pass == 0) {
-      atomicMax(&best_key[v], key);
-    } else if (key == best_key[v]) {
-      uint64_t prank = 0;  // colex rank of the parent set S \ {v_i}
-      uint32_t pos = 1;
-      for (uint32_t j = 0; j < k; ++j) {
-        if (j == i) continue;
-        prank += binom[vars[j] * (KMAX + 1) + pos];
-        ++pos;
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < nsubsets;
+       t += (uint64_t)gridDim.x * 256) {
+    uint32_t vars[KMAX];
+    uint64_t rem = t;
+    for (uint32_t j = k; j >= 1; --j) {
+      const uint32_t v = unrank_step(binom, n, j, rem);
+      vars[j - 1] = v;
+      rem -= binom[v * (KMAX + 1) + j];
+    }
+    for (uint32_t i = 0; i < k; ++i) {
+      const double sc = scores[t * k + i];
+      if (!(sc > -INFINITY)) continue;  // -inf fill (other shard) or NaN
+      const unsigned long long key = ordered_key(sc);
+      const uint32_t v = vars[i];
+      if (pass == 0) {
+        if (use_lds) atomicMax(&s_best[v], key);
+        else atomicMax(&best_key[v], key);
+      } else if (key == best_key[v]) {
+        uint64_t prank = 0;  // colex rank of the parent set S \ {v_i}
+        uint32_t pos = 1;
+        for (uint32_t j = 0; j < k; ++j) {
+          if (j == i) continue;
+          prank += binom[vars[j] * (KMAX + 1) + pos];
+          ++pos;
+        }
+        const unsigned long long id = ((unsigned long long)(k - 1) << 56) | prank;
+        if (use_lds) atomicMin(&s_best[v], id);
+        else atomicMin(&best_id[v], id);
       }
-      atomicMin(&best_id[v], ((unsigned long long)(k - 1) << 56) | prank);
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (uint32_t v = threadIdx.x; v < n; v += 256) {
+      const unsigned long long x = s_best[v];
+      if (pass == 0) {
+        if (x) atomicMax(&best_key[v], x);
+      } else if (x != ~0ull) {
+        atomicMin(&best_id[v], x);
+      }
     }
   }
 }
@@ -615,6 +694,11 @@ struct Plan {
   DevBuf<uint64_t> rowoff;      // by colex rank of the kr-subset
   uint64_t counted_epoch = 0;   // data epoch the counters in `red` belong to
   uint64_t total_items = 0;
+  // per-table functional G[colex rank] of this plan's tables (see score_reduced_kernel)
+  DevBuf<double> G;
+  uint64_t g_epoch = 0;
+  int g_kind = -1;
+  double g_ess = 0.0;
 };
 
 }  // namespace
@@ -939,6 +1023,26 @@ obnsl_status ensure_counts(obnsl_data* d, Plan* plan) {
   return OBNSL_OK;
 }
 
+// Reduced mode: expand + evaluate the functional G for every table of `plan`
+// (and the scores, when `scores` is given) -- one score_reduced_kernel launch.
+obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views, uint32_t k,
+                            uint64_t max_cells, obnsl_score_kind kind, double ess,
+                            const double* gprev, double g0, double* scores) {
+  HIP_TRY(plan->G.ensure(std::max<uint64_t>(binom_host(d->n, k), 1)));
+  const Batch* b = plan->batches[0].get();
+  if (b->ntables) {
+    hipLaunchKernelGGL(score_reduced_kernel, dim3((uint32_t)b->ntables), dim3(64),
+                       (size_t)max_cells * sizeof(uint32_t), d->stream, views, b->rgs.p, b->nrgs, k,
+                       b->ntables, d->d_card.p, d->d_binom.p, (uint32_t)d->N, (int)kind, ess,
+                       plan->G.p, gprev, g0, scores);
+    HIP_TRY(hipGetLastError());
+  }
+  plan->g_epoch = d->epoch;
+  plan->g_kind = (int)kind;
+  plan->g_ess = ess;
+  return OBNSL_OK;
+}
+
 obnsl_status check_kind(obnsl_score_kind kind) {
   if (kind == OBNSL_SCORE_BDEU || kind == OBNSL_SCORE_BIC) return OBNSL_OK;
   return fail(OBNSL_ERR_UNSUPPORTED, "Unsupported score type.");
@@ -1221,14 +1325,25 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
       views.v[j].kr = use->kr;
       views.v[j].kc = use->kc;
     }
-    const Batch* b = own->batches[0].get();
-    if (b->ntables) {
-      hipLaunchKernelGGL(score_reduced_kernel, dim3((uint32_t)b->ntables), dim3(64),
-                         (size_t)max_cells * sizeof(uint32_t), d->stream, views, b->rgs.p, b->nrgs,
-                         k, b->ntables, d->d_card.p, d->d_binom.p, (uint32_t)d->N, (int)kind, ess,
-                         d_scores);
-      HIP_TRY(hipGetLastError());
+    // G of the next smaller size, over ALL its subsets (cached per data epoch)
+    const double N_d = (double)d->N;
+    const double g0 = kind == OBNSL_SCORE_BDEU ? std::lgamma(N_d + ess) - std::lgamma(ess)
+                                               : N_d * std::log(N_d);
+    const double* gprev = nullptr;
+    if (k > 1) {
+      Plan* prev = nullptr;
+      st = build_plan(d, k - 1, 0, 1, true, &prev);
+      if (st != OBNSL_OK) return st;
+      if (!(prev->g_epoch == d->epoch && prev->g_kind == (int)kind && prev->g_ess == ess)) {
+        ReducedViews pv = views;  // sizes 1..k-1 are the full plans already
+        std::memset(&pv.v[k], 0, sizeof(SizeView));
+        st = run_functional(d, prev, pv, k - 1, max_cells, kind, ess, nullptr, 0.0, nullptr);
+        if (st != OBNSL_OK) return st;
+      }
+      gprev = prev->G.p;
     }
+    st = run_functional(d, own, views, k, max_cells, kind, ess, gprev, g0, d_scores);
+    if (st != OBNSL_OK) return st;
   } else {
     Plan* plan = nullptr;
     st = build_plan(d, k, shard, num_shards, false, &plan);
@@ -1329,7 +1444,8 @@ obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
   for (int pass = 0; pass < 2; ++pass)
     for (uint32_t k = 1; k <= max_parents + 1; ++k) {
       const uint64_t nsub = binom_host(d->n, k);
-      hipLaunchKernelGGL(best_parents_kernel, dim3((uint32_t)((nsub + 255) / 256)), dim3(256), 0,
+      const uint32_t bgrid = (uint32_t)std::min<uint64_t>((nsub + 255) / 256, 512);
+      hipLaunchKernelGGL(best_parents_kernel, dim3(bgrid), dim3(256), 0,
                          d->stream, d_scores[k - 1], nsub, k, d->n, d->d_binom.p, key.p, id.p, pass);
     }
   HIP_TRY(hipGetLastError());
