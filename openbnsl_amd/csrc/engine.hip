@@ -43,7 +43,6 @@ namespace {
 
 constexpr int KMAX = OBNSL_MAX_SUBSET;  // largest subset size
 constexpr int KSIDE = 4;                // largest kr / kc
-constexpr int BM = 128, BN = 128;       // C tile of one workgroup
 constexpr int KCW = 32;                 // 32-bit words of the contraction per LDS slab
 constexpr int LDS_STRIDE = KCW + 4;     // padded slab row (words): conflict-free b128 reads
 constexpr uint64_t BATCH_CELL_CAP = 1ull << 30;  // counters per batch (4 GiB)
@@ -132,31 +131,34 @@ __device__ __forceinline__ uint4 and4(uint4 a, uint4 b) {
 }
 
 // C[row][col] += sum over this split's words of popc(A[row][w] & B[col][w]).
-// 256 threads; thread (tm, tn) owns rows tm + 16 i and columns tn + 16 j
-// (i, j < 8), which makes every ds_read_b128 of the compute phase
+// 256 threads; a workgroup owns a (16 TT) x (16 TT) tile of C (TT = 8: 128 x 128,
+// TT = 4: 64 x 64); thread (tm, tn) owns rows tm + 16 i and columns tn + 16 j
+// (i, j < TT), which makes every ds_read_b128 of the compute phase
 // bank-conflict free with the 36-word slab stride.
-template <int KR, int KC>
+template <int KR, int KC, int TT>
 __global__ __launch_bounds__(256) void bitgemm_kernel(
     const uint32_t* __restrict__ planes, uint32_t wp, const RowDesc* __restrict__ rows,
     uint32_t nrows, const ColDesc* __restrict__ cols, uint32_t ncols_total,
     const uint2* __restrict__ items, uint32_t nitems, uint32_t* __restrict__ counts,
     uint32_t steps_total, uint32_t steps_per_split, int use_atomics) {
+  constexpr int TB = 16 * TT;   // tile edge
+  constexpr int NP = TB / 32;   // staging passes: 256 threads fill 32 slab rows per pass
   // two slabs of A and of B: slab (s & 1) is read while slab ((s + 1) & 1) is
   // filled, one barrier per step.  One array (a second __shared__ object beside
   // it could make the compiler drain loads before every LDS read).
-  __shared__ __attribute__((aligned(16))) uint32_t smem[2 * (BM + BN) * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t smem[2 * 2 * TB * LDS_STRIDE];
 
   const uint32_t item_id = blockIdx.x % nitems;
   const uint32_t split = blockIdx.x / nitems;
   const uint2 it = items[item_id];
-  const uint32_t row0 = it.x * BM, col0 = it.y * BN;
+  const uint32_t row0 = it.x * TB, col0 = it.y * TB;
   const uint32_t tid = threadIdx.x;
 
   // staging role: 8 threads cover one 32-word slab row with one uint4 each
   const uint32_t q = tid & 7, rl = tid >> 3;
-  uint32_t aoff[4][KR], boff[4][KC];
+  uint32_t aoff[NP][KR], boff[NP][KC];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const uint32_t r = min(row0 + rl + 32 * p, nrows - 1);
     const uint32_t c = min(col0 + rl + 32 * p, ncols_total - 1);
 #pragma unroll
@@ -167,20 +169,20 @@ __global__ __launch_bounds__(256) void bitgemm_kernel(
   const uint32_t st_off = rl * LDS_STRIDE + q * 4;  // this thread's uint4 in a slab (row rl)
 
   const uint32_t tn = tid & 15, tm = tid >> 4;
-  uint32_t acc[8][8];
+  uint32_t acc[TT][TT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < TT; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = 0;
+    for (int j = 0; j < TT; ++j) acc[i][j] = 0;
 
   const uint32_t step_lo = split * steps_per_split;
   const uint32_t step_hi = min(step_lo + steps_per_split, steps_total);
-  uint4 ga[4][KR], gb[4][KC];  // raw plane words of the next slab, in flight during compute
+  uint4 ga[NP][KR], gb[NP][KC];  // raw plane words of the next slab, in flight during compute
 
   auto issue_loads = [&](uint32_t step) {
     const uint32_t w0 = step * KCW;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int j = 0; j < KR; ++j)
         ga[p][j] = *reinterpret_cast<const uint4*>(planes + aoff[p][j] + w0);
@@ -190,10 +192,10 @@ __global__ __launch_bounds__(256) void bitgemm_kernel(
     }
   };
   auto write_slab = [&](uint32_t buf) {
-    uint32_t* sA = smem + buf * (BM + BN) * LDS_STRIDE;
-    uint32_t* sB = sA + BM * LDS_STRIDE;
+    uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
+    uint32_t* sB = sA + TB * LDS_STRIDE;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
       uint4 va = ga[p][0], vb = gb[p][0];
 #pragma unroll
       for (int j = 1; j < KR; ++j) va = and4(va, ga[p][j]);
@@ -213,21 +215,21 @@ __global__ __launch_bounds__(256) void bitgemm_kernel(
     const uint32_t buf = (step - step_lo) & 1;
     const bool more = step + 1 < step_hi;
     if (more) issue_loads(step + 1);
-    const uint32_t* sA = smem + buf * (BM + BN) * LDS_STRIDE;
-    const uint32_t* sB = sA + BM * LDS_STRIDE;
+    const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
+    const uint32_t* sB = sA + TB * LDS_STRIDE;
 #pragma unroll 1
     for (int kq = 0; kq < KCW / 4; ++kq) {
-      uint4 a[8], b[8];
+      uint4 a[TT], b[TT];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < TT; ++i)
         a[i] = *reinterpret_cast<const uint4*>(&sA[(tm + 16 * i) * LDS_STRIDE + kq * 4]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < TT; ++j)
         b[j] = *reinterpret_cast<const uint4*>(&sB[(tn + 16 * j) * LDS_STRIDE + kq * 4]);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < TT; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < TT; ++j) {
           acc[i][j] += __popc(a[i].x & b[j].x);
           acc[i][j] += __popc(a[i].y & b[j].y);
           acc[i][j] += __popc(a[i].z & b[j].z);
@@ -239,17 +241,20 @@ __global__ __launch_bounds__(256) void bitgemm_kernel(
   }
 
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < TT; ++i) {
     const uint32_t r = row0 + tm + 16 * i;
     if (r >= nrows) continue;
     const RowDesc rd = rows[r];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < TT; ++j) {
       const uint32_t c = col0 + tn + 16 * j;
       if (c >= rd.ncols) continue;
       uint32_t* dst = counts + rd.out_base + (uint64_t)c * rd.M;
-      if (use_atomics) atomicAdd(dst, acc[i][j]);
-      else *dst = acc[i][j];
+      if (use_atomics) {
+        if (acc[i][j]) atomicAdd(dst, acc[i][j]);
+      } else {
+        *dst = acc[i][j];
+      }
     }
   }
 }
@@ -685,6 +690,7 @@ struct Batch {
 struct Plan {
   uint32_t k = 0, kr = 0, kc = 0;
   bool reduced = false;         // rows/columns cover states 1..r-1 only (see score_reduced_kernel)
+  uint32_t tile = 128;          // C tile edge of the bit-GEMM launches of this plan
   DevBuf<ColDesc> cols;
   DevBuf<ColGroupDesc> cgs;
   uint32_t ncols_total = 0;
@@ -711,6 +717,7 @@ struct obnsl_data {
   std::vector<uint32_t> card, plane_base;
   DevBuf<uint8_t> codes;
   DevBuf<uint32_t> planes, d_card, d_plane_base, counts;
+  DevBuf<unsigned long long> best_key, best_id;  // per-node arg-max scratch of obnsl_best_parents
   DevBuf<uint64_t> d_binom;
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, bool>, std::unique_ptr<Plan>> plans;
   uint64_t epoch = 1;                                 // bumped whenever the planes are rebuilt
@@ -910,14 +917,30 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
       tables += rg.ncolgroups;
       ++g;
     }
-    // tiles: (row tile i, column tile j) for j below the tile's column limit
+    // tiles: (row tile i, column tile j) for j below the tile's column limit.
+    // 128 x 128 tiles when there are enough of them to fill the chip without
+    // splitting the contraction finely, 64 x 64 otherwise (better fill of the
+    // staircase and of thin problems, 4x fewer counters flushed per workgroup).
+    auto make_tiles = [&](uint32_t tb, std::vector<std::pair<uint32_t, uint2>>& out) {
+      out.clear();
+      const uint32_t ntr = (uint32_t)((rows.size() + tb - 1) / tb);
+      for (uint32_t i = 0; i < ntr; ++i) {
+        const size_t last = std::min<size_t>((size_t)(i + 1) * tb, rows.size()) - 1;
+        const uint32_t lim = rows[last].ncols;
+        for (uint32_t j = 0; j * tb < lim; ++j)
+          out.push_back({std::min<uint32_t>(lim - j * tb, tb), make_uint2(i, j)});
+      }
+    };
     std::vector<std::pair<uint32_t, uint2>> tiles;
-    const uint32_t ntr = (uint32_t)((rows.size() + BM - 1) / BM);
-    for (uint32_t i = 0; i < ntr; ++i) {
-      const size_t last = std::min<size_t>((size_t)(i + 1) * BM, rows.size()) - 1;
-      const uint32_t lim = rows[last].ncols;
-      for (uint32_t j = 0; j * BN < lim; ++j)
-        tiles.push_back({std::min<uint32_t>(lim - j * BN, BN), make_uint2(i, j)});
+    static const int force_tile = [] {
+      const char* e = std::getenv("OBNSL_TILE");
+      return e ? std::atoi(e) : 0;
+    }();
+    make_tiles(128, tiles);
+    plan->tile = 128;
+    if (force_tile == 64 || (force_tile == 0 && tiles.size() < 2048)) {
+      make_tiles(64, tiles);
+      plan->tile = 64;
     }
     std::stable_sort(tiles.begin(), tiles.end(),
                      [](const std::pair<uint32_t, uint2>& a, const std::pair<uint32_t, uint2>& b) {
@@ -964,9 +987,14 @@ obnsl_status resolve_events(obnsl_data* d) {
 template <int KR, int KC>
 void launch_bitgemm(obnsl_data* d, const Plan* p, const Batch* b, uint32_t* counts, uint32_t grid,
                     uint32_t steps_total, uint32_t steps_per_split, int atomics) {
-  hipLaunchKernelGGL((bitgemm_kernel<KR, KC>), dim3(grid), dim3(256), 0, d->stream,
-                     d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
-                     b->items.p, b->nitems, counts, steps_total, steps_per_split, atomics);
+  if (p->tile == 128)
+    hipLaunchKernelGGL((bitgemm_kernel<KR, KC, 8>), dim3(grid), dim3(256), 0, d->stream,
+                       d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
+                       b->items.p, b->nitems, counts, steps_total, steps_per_split, atomics);
+  else
+    hipLaunchKernelGGL((bitgemm_kernel<KR, KC, 4>), dim3(grid), dim3(256), 0, d->stream,
+                       d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
+                       b->items.p, b->nitems, counts, steps_total, steps_per_split, atomics);
 }
 
 // One bit-GEMM launch (timed with an event pair) filling `counts` for one batch.
@@ -1435,7 +1463,8 @@ obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   obnsl_status st = set_device(d->device);
   if (st != OBNSL_OK) return st;
-  DevBuf<unsigned long long> key, id;
+  DevBuf<unsigned long long>& key = d->best_key;
+  DevBuf<unsigned long long>& id = d->best_id;
   HIP_TRY(key.ensure(d->n));
   HIP_TRY(id.ensure(d->n));
   const uint32_t gb = (d->n + 255) / 256;
