@@ -53,7 +53,7 @@ def cpu_baseline(codes, card, names, max_parents, budget_s=20.0):
     k = max_parents + 1
     n = codes.shape[0]
     rng = np.random.default_rng(0)
-    ncols = min(n, 8)
+    ncols = min(n, 12)
     cols = sorted(rng.choice(n, size=ncols, replace=False).tolist())
     subs_all = oracle.enumerate_subsets(ncols, min(k, ncols))
     ref = oracle.ref()
@@ -101,17 +101,25 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from openbnsl_amd import distributed as obd, engine
+    from openbnsl_amd import engine
+    from openbnsl_amd.pipeline import HotPath
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal on a box with fewer GPUs than ranks: OBNSL_BENCH_BACKEND=gloo maps
+    # every rank to an existing device and exchanges through host memory
+    backend = os.environ.get("OBNSL_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     spec = WORKLOADS[args.workload]
     codes, card, names = make_data(spec)
@@ -119,40 +127,29 @@ def main():
     mp = spec["max_parents"]
     kind = engine.BDEU if spec["score"] == "bdeu" else engine.BIC
 
-    data = engine.Data(codes, card, device=local_rank)
-    stream = torch.cuda.current_stream()
-    data.set_stream(stream.cuda_stream)
-    tables = [torch.full((data.num_subsets(k) * k,), float("-inf"), dtype=torch.float64, device=dev)
-              for k in range(1, mp + 2)]
-    ptrs = [t.data_ptr() for t in tables]
-    n_scores = sum(data.num_subsets(k) * k for k in range(1, mp + 2))
+    hot = HotPath(codes, card, mp, kind=kind, ess=1.0, rank=rank, world=world, device_index=dev_index)
+    data = hot.data
+    tables = hot.tables
+    n_scores = hot.scores_per_pass
+    step = hot.step
 
-    def step():
-        data.pack()
-        for k in range(1, mp + 2):
-            data.score_all_device(k, ptrs[k - 1], kind=kind, ess=1.0, shard=rank, num_shards=world)
-        sc, sz, rk = data.best_parents(ptrs, mp)
+    def barrier():
+        torch.cuda.synchronize()
         if world > 1:
-            sc, sz, rk = obd.allgather_best(sc, sz, rk, device=dev)
-        return sc, sz, rk
+            dist.barrier()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         best = step()
     data.kernel_time(mp + 1, reset=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         best = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -202,7 +199,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    data.close()
+    hot.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,0 +1,76 @@
+"""The whole hot path as one object: what one rank does per pass.
+
+    pack -> for k = 1..max_parents+1: count + score this rank's shard of the
+    size-k subsets -> per-node best parent sets of the shard -> (world > 1)
+    all-gather of those records and the deterministic combine.
+
+Used by bench.py (timed) and by the multi-rank tests.  PyTorch provides the
+device score tables, the stream and torch.distributed; every kernel launched is
+the engine's (include/obnsl_engine.h)."""
+import numpy as np
+
+from . import distributed as obd
+from . import engine
+
+
+class HotPath:
+    def __init__(self, codes, card, max_parents, kind=engine.BDEU, ess=1.0, rank=0, world=1,
+                 device_index=0):
+        import torch
+        self.torch = torch
+        self.rank, self.world = rank, world
+        self.mp, self.kind, self.ess = max_parents, kind, ess
+        self.dev = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.dev)
+        self.data = engine.Data(codes, card, device=device_index)
+        self.data.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.n, self.N = self.data.n, self.data.N
+        # one score table per subset size; entries of other ranks' shards stay -inf
+        self.tables = [torch.full((self.data.num_subsets(k) * k,), float("-inf"),
+                                  dtype=torch.float64, device=self.dev)
+                       for k in range(1, max_parents + 2)]
+        self.ptrs = [t.data_ptr() for t in self.tables]
+        self.scores_per_pass = sum(self.data.num_subsets(k) * k for k in range(1, max_parents + 2))
+
+    def step(self):
+        """One pass; returns (best_score, best_size, best_rank) per node, combined
+        over all ranks when world > 1."""
+        d = self.data
+        d.pack()
+        for k in range(1, self.mp + 2):
+            d.score_all_device(k, self.ptrs[k - 1], kind=self.kind, ess=self.ess,
+                               shard=self.rank, num_shards=self.world)
+        sc, sz, rk = d.best_parents(self.ptrs, self.mp)
+        if self.world > 1:
+            import torch.distributed as dist
+            on_gpu = dist.get_backend() == "nccl"
+            sc, sz, rk = obd.allgather_best(sc, sz, rk, device=self.dev if on_gpu else None)
+        return sc, sz, rk
+
+    def shard_scores(self, k):
+        """Number of finite entries this rank holds in the size-k table."""
+        return int(self.torch.isfinite(self.tables[k - 1]).sum().item())
+
+    def parents_of(self, size, rank):
+        return [engine.unrank(int(r), int(s)) for s, r in zip(size, rank)]
+
+    def close(self):
+        self.data.close()
+
+
+def best_parents_reference(score_tables, n):
+    """Brute-force per-node best over host score tables [C(n,k), k] (tests)."""
+    import oracle
+    best = {}
+    for k, tab in enumerate(score_tables, start=1):
+        subs = oracle.enumerate_subsets(n, k)
+        for t, s in enumerate(subs):
+            for i, v in enumerate(s):
+                ps = [int(x) for x in s if x != v]
+                key = (tab[t, i], -(k - 1), -engine.rank(ps))
+                if int(v) not in best or key > best[int(v)]:
+                    best[int(v)] = key
+    sc = np.array([best[v][0] for v in range(n)])
+    sz = np.array([-best[v][1] for v in range(n)], dtype=np.uint32)
+    rk = np.array([-best[v][2] for v in range(n)], dtype=np.uint64)
+    return sc, sz, rk
