@@ -110,6 +110,13 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
                              uint32_t shard, uint32_t num_shards, double* scores_out,
                              int out_on_device);
 
+/* Scheduling hint with no counterpart in the reference: queue the counting of
+ * every subset size 1..kmax at once (sizes below kmax whole, size kmax for this
+ * shard), the small launches on an internal second stream so that they overlap
+ * the large one.  obnsl_score_all calls that follow, on the same row bitmaps,
+ * reuse these counts.  Calling it is optional; results are the same without. */
+obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_t num_shards);
+
 /* Number of size-k subsets, C(num_vars, k), and of scores, k * C(num_vars, k). */
 obnsl_status obnsl_num_subsets(const obnsl_data* d, uint32_t k, uint64_t* num_subsets);
 

@@ -294,6 +294,31 @@ __global__ __launch_bounds__(256) void count_single_kernel(
 }
 
 // ------------------------------------------------------------------ scoring
+// lgamma(x) for x > 0: shift the argument up to >= 16 with the recurrence
+// lgamma(x) = lgamma(x + m) - ln(x (x+1) ... (x+m-1)), then the Stirling series
+// through the 1/x^11 term (the next term is < 2e-18 at x = 16).  Agrees with
+// glibc's lgamma to ~2e-14 absolute over the arguments the scores use (counts
+// plus a positive prior); far smaller and lighter on registers than the
+// general-purpose library routine, which matters for the scorer's occupancy.
+__device__ __forceinline__ double lgamma_pos(double x) {
+  double shift = 0.0;
+  if (x < 16.0) {
+    double p = 1.0;
+    while (x < 16.0) {
+      p *= x;
+      x += 1.0;
+    }
+    shift = log(p);
+  }
+  const double inv = 1.0 / x, inv2 = inv * inv;
+  const double ser =
+      inv * (1.0 / 12.0 -
+             inv2 * (1.0 / 360.0 -
+                     inv2 * (1.0 / 1260.0 -
+                             inv2 * (1.0 / 1680.0 - inv2 * (1.0 / 1188.0 - inv2 * (691.0 / 360360.0))))));
+  return (x - 0.5) * log(x) - x + 0.91893853320467274178 + ser - shift;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -315,14 +340,14 @@ __device__ void score_table(const uint32_t* __restrict__ cnt, uint32_t k, const 
   double a_ijk = 0.0, lg_a_ijk = 0.0;
   if (kind == OBNSL_SCORE_BDEU) {
     a_ijk = ess / (double)cells;
-    lg_a_ijk = lgamma(a_ijk);
+    lg_a_ijk = lgamma_pos(a_ijk);
   }
   double t1 = 0.0, tot = 0.0;
   for (uint32_t c = lane; c < cells; c += 64) {
     const uint32_t nijk = cnt[c];
     if (nijk == 0) continue;
     if (kind == OBNSL_SCORE_BDEU) {
-      t1 += lgamma((double)nijk + a_ijk) - lg_a_ijk;
+      t1 += lgamma_pos((double)nijk + a_ijk) - lg_a_ijk;
     } else {
       t1 += (double)nijk * log((double)nijk);
       tot += (double)nijk;
@@ -337,7 +362,7 @@ __device__ void score_table(const uint32_t* __restrict__ cnt, uint32_t k, const 
     double a_ij = 0.0, lg_a_ij = 0.0;
     if (kind == OBNSL_SCORE_BDEU) {
       a_ij = a_ijk * (double)r;
-      lg_a_ij = lgamma(a_ij);
+      lg_a_ij = lgamma_pos(a_ij);
     }
     double t2 = 0.0;
     for (uint32_t j = lane; j < q; j += 64) {
@@ -346,7 +371,7 @@ __device__ void score_table(const uint32_t* __restrict__ cnt, uint32_t k, const 
       uint32_t nij = 0;
       for (uint32_t s = 0; s < r; ++s) nij += cnt[base + s * w];
       if (nij == 0) continue;
-      if (kind == OBNSL_SCORE_BDEU) t2 += lgamma((double)nij + a_ij) - lg_a_ij;
+      if (kind == OBNSL_SCORE_BDEU) t2 += lgamma_pos((double)nij + a_ij) - lg_a_ij;
       else t2 += (double)nij * log((double)nij);
     }
     t2 = wave_sum(t2);
@@ -411,6 +436,13 @@ __global__ __launch_bounds__(256) void score_tables_kernel(
 // then turn "any" into "state 0" one variable at a time,
 //   F(.., 0, ..) = E(.., any, ..) - sum_{s>=1} E(.., s, ..),
 // which is exact integer arithmetic (inclusion-exclusion).
+// x / r for x < 2^20 and 1 <= r <= 4096 without the ~35-instruction integer
+// division: floor((x + 0.5) * (1/r)) is exact there (the 0.5 keeps exact
+// multiples away from the rounding edge; float carries x + 0.5 exactly).
+__device__ __forceinline__ uint32_t fast_div(uint32_t x, float inv_r) {
+  return (uint32_t)(((float)x + 0.5f) * inv_r);
+}
+
 struct SizeView {            // where the reduced tables of one subset size live
   const uint32_t* red;       // counters
   const uint64_t* rowoff;    // first counter of a row group, by colex rank of its kr-subset
@@ -425,7 +457,7 @@ struct ReducedViews {
 // tables of the 2^k - 1 non-empty sub-subsets, k in-place passes, then the k scores.
 //
 // Scores come from a per-table functional: with
-//   G(T) = sum over non-zero cells c of T of [lgamma(N_c + ess/cells(T)) - lgamma(ess/cells(T))]
+//   G(T) = sum over non-zero cells c of T of [lgamma_pos(N_c + ess/cells(T)) - lgamma_pos(ess/cells(T))]
 // the reference's BDeu local score (include/score/local_score.h:38-61) is
 //   score(v | P) = G(P + v) - G(P),
 // because the parent-configuration counts N_ij of the table over P + v are the
@@ -436,127 +468,162 @@ struct ReducedViews {
 // subset size (g0 for the empty set).  scores may be null (G only).
 __global__ __launch_bounds__(64) void score_reduced_kernel(
     ReducedViews views, const RowGroupDesc* __restrict__ rgs, uint32_t nrgs, uint32_t k,
-    uint64_t ntables, const uint32_t* __restrict__ card, const uint64_t* __restrict__ binom,
-    uint32_t num_rows, int kind, double ess, double* __restrict__ G,
-    const double* __restrict__ Gprev, double g0, double* __restrict__ scores) {
+    uint64_t ntables, uint32_t tables_per_wg, const uint32_t* __restrict__ card,
+    const uint64_t* __restrict__ binom, uint32_t num_rows, int kind, double ess,
+    double* __restrict__ G, const double* __restrict__ Gprev, double g0,
+    double* __restrict__ scores) {
   extern __shared__ __attribute__((aligned(16))) uint32_t E[];
   __shared__ SizeView sv[KMAX + 1];
   __shared__ uint32_t s_vars[KMAX], s_cards[KMAX];
+  __shared__ uint64_t pat_base[1 << KMAX];  // first counter of the reduced table of a support pattern
   const uint32_t lane = threadIdx.x;
 #pragma unroll
   for (int j = 0; j <= KMAX; ++j)
     if (lane == (uint32_t)j) sv[j] = views.v[j];
-  const uint64_t t = blockIdx.x;
-  uint32_t lo = 0, hi = nrgs - 1;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi + 1) >> 1;
-    if (rgs[mid].tbl_start <= t) lo = mid;
+  const uint64_t t0 = (uint64_t)blockIdx.x * tables_per_wg;
+  const uint64_t t1 = min(t0 + (uint64_t)tables_per_wg, ntables);
+  // row group of the first table; consecutive tables advance through the groups
+  uint32_t g = 0, hi = nrgs - 1;
+  while (g < hi) {
+    const uint32_t mid = (g + hi + 1) >> 1;
+    if (rgs[mid].tbl_start <= t0) g = mid;
     else hi = mid - 1;
   }
-  const RowGroupDesc rg = rgs[lo];
-  const uint32_t gamma = (uint32_t)(t - rg.tbl_start);
+  RowGroupDesc rg = rgs[g];
   const uint32_t kc = k / 2, kr = k - kc;
-  uint32_t vars[KMAX], cards[KMAX];
   __syncthreads();
-  if (kc > 0) {
-    const ColGroupDesc cg = sv[k].cgs[gamma];
-    for (uint32_t j = 0; j < kc; ++j) vars[j] = cg.vars[j];
-  }
-  for (uint32_t j = 0; j < kr; ++j) vars[kc + j] = rg.vars[j];
-  uint32_t cells = 1;
-  for (uint32_t i = 0; i < k; ++i) {
-    cards[i] = card[vars[i]];
-    cells *= cards[i];
-  }
+  const ColGroupDesc* __restrict__ own_cgs = sv[k].cgs;
 
-  for (uint32_t cell = lane; cell < cells; cell += 64) {
-    uint32_t e[KMAX];
-    uint32_t rem = cell, nz = 0;
-    for (int i = (int)k - 1; i >= 0; --i) {
-      e[i] = rem % cards[i];
-      rem /= cards[i];
-      nz += e[i] != 0;
+  for (uint64_t t = t0; t < t1; ++t) {
+    while (t >= rg.tbl_start + rg.ncolgroups) rg = rgs[++g];
+    const uint32_t gamma = (uint32_t)(t - rg.tbl_start);
+    // (fixed-trip loops guarded by i < k keep these small arrays in registers)
+    uint32_t vars[KMAX], cards[KMAX];
+    float inv_card[KMAX];
+    ColGroupDesc cg;
+    if (kc > 0) cg = own_cgs[gamma];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      vars[i] = 0;
+      if (i < KSIDE && i < (int)kc) vars[i] = cg.vars[i];
+#pragma unroll
+      for (int j = 0; j < KSIDE; ++j)
+        if (i == (int)kc + j && j < (int)kr) vars[i] = rg.vars[j];
     }
-    uint32_t val = num_rows;
-    if (nz) {
-      const SizeView s = sv[nz];
+    uint32_t cells = 1;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      cards[i] = 1;
+      inv_card[i] = 1.0f;
+      if (i < (int)k) {
+        cards[i] = card[vars[i]];
+        inv_card[i] = 1.0f / (float)cards[i];
+        cells *= cards[i];
+      }
+    }
+    // where the reduced table of each non-empty support pattern starts: the table
+    // of T (|T| = j) lives in size j's layout, row side = its kr_j largest variables
+    for (uint32_t pat = lane + 1; pat < (1u << k); pat += 64) {
+      const SizeView s = sv[__popc(pat)];
       uint64_t colrank = 0, rowrank = 0;
-      uint32_t keycol = 0, keyrow = 0, mred = 1, p = 0;
-      for (uint32_t i = 0; i < k; ++i) {
-        if (e[i] == 0) continue;
+      uint32_t mred = 1, p = 0;
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i) {
+        if (i >= (int)k || !(pat >> i & 1)) continue;
         ++p;
-        const uint32_t rad = cards[i] - 1;
         if (p <= s.kc) {
           colrank += binom[vars[i] * (KMAX + 1) + p];
-          keycol = keycol * rad + (e[i] - 1);
         } else {
           rowrank += binom[vars[i] * (KMAX + 1) + (p - s.kc)];
-          keyrow = keyrow * rad + (e[i] - 1);
-          mred *= rad;
+          mred *= cards[i] - 1;
         }
       }
       const uint32_t col_before = s.kc ? s.cgs[colrank].col_before : 0;
-      val = s.red[s.rowoff[rowrank] + (uint64_t)(col_before + keycol) * mred + keyrow];
-    }
-    E[cell] = val;
-  }
-  __syncthreads();
-  uint32_t w = 1;
-  for (int i = (int)k - 1; i >= 0; --i) {
-    const uint32_t r = cards[i];
-    const uint32_t lines = cells / r;
-    for (uint32_t l = lane; l < lines; l += 64) {
-      const uint32_t h = l / w, lo_ = l - h * w;
-      const uint32_t base = h * (r * w) + lo_;
-      uint32_t s = 0;
-      for (uint32_t st = 1; st < r; ++st) s += E[base + st * w];
-      E[base] -= s;
+      pat_base[pat] = s.rowoff[rowrank] + (uint64_t)col_before * mred;
     }
     __syncthreads();
-    w *= r;
-  }
-  const uint64_t rank = rg.rank_part + gamma;
-  double g = 0.0;
-  if (kind == OBNSL_SCORE_BDEU) {
-    const double a = ess / (double)cells;
-    const double lg_a = lgamma(a);
-    for (uint32_t c = lane; c < cells; c += 64) {
-      const uint32_t nc = E[c];
-      if (nc) g += lgamma((double)nc + a) - lg_a;
-    }
-  } else {
-    for (uint32_t c = lane; c < cells; c += 64) {
-      const uint32_t nc = E[c];
-      if (nc) g += (double)nc * log((double)nc);
-    }
-  }
-  g = wave_sum(g);
-  if (lane == 0) G[rank] = g;
-  if (scores == nullptr) return;
-  for (uint32_t i = 0; i < k; ++i)
-    if (lane == i) {
-      s_vars[i] = vars[i];
-      s_cards[i] = cards[i];
-    }
-  __syncthreads();
-  if (lane < k) {
-    double gp = g0;
-    if (k > 1) {
-      uint64_t sub = 0;
-      uint32_t pos = 1;
-      for (uint32_t j = 0; j < k; ++j) {
-        if (j == lane) continue;
-        sub += binom[s_vars[j] * (KMAX + 1) + pos];
-        ++pos;
+    // E(e): digit 0 = "any".  Within a pattern the counter index is the mixed-radix
+    // number of the non-zero digits (radix r - 1, first variable most significant).
+    for (uint32_t cell = lane; cell < cells; cell += 64) {
+      uint32_t rem = cell, pat = 0, key = 0, mul = 1;
+#pragma unroll
+      for (int i = KMAX - 1; i >= 0; --i) {
+        if (i >= (int)k) continue;
+        const uint32_t qt = fast_div(rem, inv_card[i]);
+        const uint32_t e = rem - qt * cards[i];
+        rem = qt;
+        if (e) {
+          pat |= 1u << i;
+          key += (e - 1) * mul;
+          mul *= cards[i] - 1;
+        }
       }
-      gp = Gprev[sub];
+      E[cell] = pat ? sv[__popc(pat)].red[pat_base[pat] + key] : num_rows;
     }
-    double sc = g - gp;
-    if (kind == OBNSL_SCORE_BIC) {
-      const uint32_t r = s_cards[lane];
-      sc -= 0.5 * log((double)num_rows) * (double)(cells / r) * (double)(r - 1);
+    __syncthreads();
+    uint32_t w = 1;
+#pragma unroll
+    for (int i = KMAX - 1; i >= 0; --i) {
+      if (i >= (int)k) continue;
+      const uint32_t r = cards[i];
+      const uint32_t lines = fast_div(cells, inv_card[i]);
+      const float inv_w = 1.0f / (float)w;
+      for (uint32_t l = lane; l < lines; l += 64) {
+        const uint32_t h = fast_div(l, inv_w), lo_ = l - h * w;
+        const uint32_t base = h * (r * w) + lo_;
+        uint32_t sum = 0;
+        for (uint32_t st = 1; st < r; ++st) sum += E[base + st * w];
+        E[base] -= sum;
+      }
+      __syncthreads();
+      w *= r;
     }
-    scores[rank * k + lane] = sc;
+    const uint64_t rank = rg.rank_part + gamma;
+    double gsum = 0.0;
+    if (kind == OBNSL_SCORE_BDEU) {
+      const double a = ess / (double)cells;
+      const double lg_a = lgamma_pos(a);
+      for (uint32_t c = lane; c < cells; c += 64) {
+        const uint32_t nc = E[c];
+        if (nc) gsum += lgamma_pos((double)nc + a) - lg_a;
+      }
+    } else {
+      for (uint32_t c = lane; c < cells; c += 64) {
+        const uint32_t nc = E[c];
+        if (nc) gsum += (double)nc * log((double)nc);
+      }
+    }
+    gsum = wave_sum(gsum);
+    if (lane == 0) G[rank] = gsum;
+    if (scores != nullptr) {
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i)
+        if (lane == (uint32_t)i && i < (int)k) {
+          s_vars[i] = vars[i];
+          s_cards[i] = cards[i];
+        }
+      __syncthreads();
+      if (lane < k) {
+        double gp = g0;
+        if (k > 1) {
+          uint64_t sub = 0;
+          uint32_t pos = 1;
+          for (uint32_t j = 0; j < k; ++j) {
+            if (j == lane) continue;
+            sub += binom[s_vars[j] * (KMAX + 1) + pos];
+            ++pos;
+          }
+          gp = Gprev[sub];
+        }
+        double sc = gsum - gp;
+        if (kind == OBNSL_SCORE_BIC) {
+          const uint32_t r = s_cards[lane];
+          sc -= 0.5 * log((double)num_rows) * (double)(cells / r) * (double)(r - 1);
+        }
+        scores[rank * k + lane] = sc;
+      }
+    }
+    __syncthreads();  // E, pat_base and s_vars are reused by the next table
   }
 }
 
@@ -721,6 +788,10 @@ struct obnsl_data {
   DevBuf<uint64_t> d_binom;
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, bool>, std::unique_ptr<Plan>> plans;
   uint64_t epoch = 1;                                 // bumped whenever the planes are rebuilt
+  hipStream_t side = nullptr;                         // second stream for obnsl_precount (default priority)
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
+  bool count_on_side = false;                         // launch_count targets `side` instead of `stream`
+  hipStream_t count_stream() const { return count_on_side ? side : stream; }
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // around each bit-GEMM launch
   std::vector<uint32_t> ev_size;                      // subset size of each pending pair
   uint32_t ev_used = 0;                               // pending pairs
@@ -731,6 +802,9 @@ struct obnsl_data {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
     }
+    if (side_fork) (void)hipEventDestroy(side_fork);
+    if (side_join) (void)hipEventDestroy(side_join);
+    if (side) (void)hipStreamDestroy(side);
   }
 };
 
@@ -988,11 +1062,11 @@ template <int KR, int KC>
 void launch_bitgemm(obnsl_data* d, const Plan* p, const Batch* b, uint32_t* counts, uint32_t grid,
                     uint32_t steps_total, uint32_t steps_per_split, int atomics) {
   if (p->tile == 128)
-    hipLaunchKernelGGL((bitgemm_kernel<KR, KC, 8>), dim3(grid), dim3(256), 0, d->stream,
+    hipLaunchKernelGGL((bitgemm_kernel<KR, KC, 8>), dim3(grid), dim3(256), 0, d->count_stream(),
                        d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
                        b->items.p, b->nitems, counts, steps_total, steps_per_split, atomics);
   else
-    hipLaunchKernelGGL((bitgemm_kernel<KR, KC, 4>), dim3(grid), dim3(256), 0, d->stream,
+    hipLaunchKernelGGL((bitgemm_kernel<KR, KC, 4>), dim3(grid), dim3(256), 0, d->count_stream(),
                        d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
                        b->items.p, b->nitems, counts, steps_total, steps_per_split, atomics);
 }
@@ -1014,7 +1088,7 @@ obnsl_status launch_count(obnsl_data* d, const Plan* plan, const Batch* b, uint3
   const uint32_t sps = (steps_total + ksplit - 1) / ksplit;
   ksplit = (steps_total + sps - 1) / sps;
   const int atomics = ksplit > 1;
-  if (atomics) HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->stream));
+  if (atomics) HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
   if (d->ev_used == d->ev.size()) {
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -1024,7 +1098,7 @@ obnsl_status launch_count(obnsl_data* d, const Plan* plan, const Batch* b, uint3
   }
   d->ev_size[d->ev_used] = plan->k;
   auto& ev = d->ev[d->ev_used++];
-  HIP_TRY(hipEventRecord(ev.first, d->stream));
+  HIP_TRY(hipEventRecord(ev.first, d->count_stream()));
   const uint32_t grid = b->nitems * ksplit;
   const uint32_t kcn = plan->kc == 0 ? 1 : plan->kc;  // kc == 0: the single ONES column
   switch (plan->kr * 10 + kcn) {
@@ -1038,7 +1112,7 @@ obnsl_status launch_count(obnsl_data* d, const Plan* plan, const Batch* b, uint3
     default: return fail(OBNSL_ERR_RUNTIME, "internal: no bit-GEMM instance");
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ev.second, d->stream));
+  HIP_TRY(hipEventRecord(ev.second, d->count_stream()));
   return OBNSL_OK;
 }
 
@@ -1059,9 +1133,19 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
   HIP_TRY(plan->G.ensure(std::max<uint64_t>(binom_host(d->n, k), 1)));
   const Batch* b = plan->batches[0].get();
   if (b->ntables) {
-    hipLaunchKernelGGL(score_reduced_kernel, dim3((uint32_t)b->ntables), dim3(64),
+    // a few consecutive tables per wavefront amortise the row-group search and
+    // the dispatch; keep at least ~16 workgroups per CU for latency hiding
+    static const uint32_t tpw_env = [] {
+      const char* e = std::getenv("OBNSL_TABLES_PER_WG");
+      return e ? (uint32_t)std::atoi(e) : 0u;
+    }();
+    uint32_t tpw = (uint32_t)std::min<uint64_t>(2, std::max<uint64_t>(1, b->ntables / 4096));
+    if (tpw_env) tpw = tpw_env;
+    const uint32_t grid = (uint32_t)((b->ntables + tpw - 1) / tpw);
+    hipLaunchKernelGGL(score_reduced_kernel, dim3(grid), dim3(64),
                        (size_t)max_cells * sizeof(uint32_t), d->stream, views, b->rgs.p, b->nrgs, k,
-                       b->ntables, d->d_card.p, d->d_binom.p, (uint32_t)d->N, (int)kind, ess,
+                       b->ntables, tpw, d->d_card.p, d->d_binom.p, (uint32_t)d->N,
+                       (int)kind, ess,
                        plan->G.p, gprev, g0, scores);
     HIP_TRY(hipGetLastError());
   }
@@ -1393,6 +1477,52 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
     HIP_TRY(hipMemcpyAsync(scores_out, d_scores, nsub * k * sizeof(double), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
   }
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_t num_shards) {
+  if (!d) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (kmax == 0 || kmax > (uint32_t)KMAX || kmax > d->n)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "subset size must be in [1, min(num_vars, OBNSL_MAX_SUBSET)]");
+  if (num_shards == 0 || shard >= num_shards)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "shard must be in [0, num_shards)");
+  obnsl_status st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  std::vector<uint32_t> sorted_card(d->card);
+  std::sort(sorted_card.rbegin(), sorted_card.rend());
+  uint64_t max_cells = 1;
+  for (uint32_t i = 0; i < kmax; ++i) max_cells *= sorted_card[i];
+  if (std::getenv("OBNSL_NO_REDUCED") || max_cells > REDUCED_MAX_CELLS) return OBNSL_OK;  // nothing to share
+  st = resolve_events(d);
+  if (st != OBNSL_OK) return st;
+  if (!d->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d->side_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d->side_join, hipEventDisableTiming));
+  }
+  // fork: the side stream starts after everything queued so far (the pack)
+  HIP_TRY(hipEventRecord(d->side_fork, d->stream));
+  HIP_TRY(hipStreamWaitEvent(d->side, d->side_fork, 0));
+  d->count_on_side = true;
+  for (uint32_t j = 1; j < kmax && st == OBNSL_OK; ++j) {
+    Plan* full = nullptr;
+    st = build_plan(d, j, 0, 1, true, &full);
+    if (st == OBNSL_OK) st = ensure_counts(d, full);
+  }
+  d->count_on_side = false;
+  if (st != OBNSL_OK) return st;
+  Plan* top = nullptr;
+  st = build_plan(d, kmax, 0, 1, true, &top);
+  if (st != OBNSL_OK) return st;
+  if (num_shards > 1 && top->total_items > 64) {
+    st = build_plan(d, kmax, shard, num_shards, true, &top);
+    if (st != OBNSL_OK) return st;
+  }
+  st = ensure_counts(d, top);
+  if (st != OBNSL_OK) return st;
+  // join: later work on the main stream sees the side stream's counts
+  HIP_TRY(hipEventRecord(d->side_join, d->side));
+  HIP_TRY(hipStreamWaitEvent(d->stream, d->side_join, 0));
   return OBNSL_OK;
 }
 

@@ -40,6 +40,7 @@ SIGNATURES = {
                                          ctypes.c_uint32, ctypes.c_int, ctypes.c_double, _f64p]),
     "obnsl_score_all": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
                                        ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_int]),
+    "obnsl_precount": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "obnsl_num_subsets": (ctypes.c_int, [_vp, ctypes.c_uint32, _u64p]),
     "obnsl_score_subsets": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, _u32p,
                                            ctypes.c_uint32, ctypes.c_uint64, _f64p]),
@@ -138,6 +139,9 @@ class Data:
 
     def pack(self):
         _check(lib.obnsl_data_pack(self._h))
+
+    def precount(self, kmax, shard=0, num_shards=1):
+        _check(lib.obnsl_precount(self._h, kmax, shard, num_shards))
 
     def num_subsets(self, k):
         return binomial(self.n, k)

@@ -37,6 +37,7 @@ class HotPath:
         over all ranks when world > 1."""
         d = self.data
         d.pack()
+        d.precount(self.mp + 1, self.rank, self.world)
         for k in range(1, self.mp + 2):
             d.score_all_device(k, self.ptrs[k - 1], kind=self.kind, ess=self.ess,
                                shard=self.rank, num_shards=self.world)
