@@ -651,18 +651,38 @@ __device__ __forceinline__ uint32_t unrank_step(const uint64_t* __restrict__ bin
 // workgroup first reduces its share in LDS (n <= BEST_LDS_VARS) and then issues
 // at most n global atomics.
 constexpr uint32_t BEST_LDS_VARS = 2048;
+struct BestArgs {                 // every subset size in one launch
+  const double* scores[KMAX];     // scores[k-1]: table of subset size k
+  uint64_t nsubsets[KMAX];
+  uint32_t block_start[KMAX + 1]; // workgroups [block_start[k-1], block_start[k]) serve size k
+  uint32_t kmax;
+};
 __global__ __launch_bounds__(256) void best_parents_kernel(
-    const double* __restrict__ scores, uint64_t nsubsets, uint32_t k, uint32_t n,
-    const uint64_t* __restrict__ binom, unsigned long long* __restrict__ best_key,
-    unsigned long long* __restrict__ best_id, int pass) {
+    BestArgs args, uint32_t n, const uint64_t* __restrict__ binom,
+    unsigned long long* __restrict__ best_key, unsigned long long* __restrict__ best_id, int pass) {
+  uint32_t k = 1;
+#pragma unroll
+  for (int j = 1; j < KMAX; ++j)
+    if ((uint32_t)j < args.kmax && blockIdx.x >= args.block_start[j]) k = j + 1;
+  const double* __restrict__ scores = nullptr;
+  uint64_t nsubsets = 0;
+  uint32_t first_block = 0, nblocks = 1;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j)
+    if ((uint32_t)j + 1 == k) {
+      scores = args.scores[j];
+      nsubsets = args.nsubsets[j];
+      first_block = args.block_start[j];
+      nblocks = args.block_start[j + 1] - args.block_start[j];
+    }
   __shared__ unsigned long long s_best[BEST_LDS_VARS];
   const bool use_lds = n <= BEST_LDS_VARS;
   if (use_lds) {
     for (uint32_t v = threadIdx.x; v < n; v += 256) s_best[v] = pass == 0 ? 0ull : ~0ull;
     __syncthreads();
   }
-  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < nsubsets;
-       t += (uint64_t)gridDim.x * 256) {
+  for (uint64_t t = (uint64_t)(blockIdx.x - first_block) * 256 + threadIdx.x; t < nsubsets;
+       t += (uint64_t)nblocks * 256) {
     uint32_t vars[KMAX];
     uint64_t rem = t;
     for (uint32_t j = k; j >= 1; --j) {
@@ -705,9 +725,13 @@ __global__ __launch_bounds__(256) void best_parents_kernel(
   }
 }
 
-__global__ void fill_u64_kernel(unsigned long long* p, unsigned long long v, uint32_t n) {
+// keys[0..n) = 0 (below every ordered score), ids[0..n) = all ones (above every id)
+__global__ void best_init_kernel(unsigned long long* keys, unsigned long long* ids, uint32_t n) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = v;
+  if (i < n) {
+    keys[i] = 0ull;
+    ids[i] = ~0ull;
+  }
 }
 
 // ------------------------------------------------------------------ host side
@@ -784,7 +808,7 @@ struct obnsl_data {
   std::vector<uint32_t> card, plane_base;
   DevBuf<uint8_t> codes;
   DevBuf<uint32_t> planes, d_card, d_plane_base, counts;
-  DevBuf<unsigned long long> best_key, best_id;  // per-node arg-max scratch of obnsl_best_parents
+  DevBuf<unsigned long long> best_key;           // per-node arg-max scratch of obnsl_best_parents
   DevBuf<uint64_t> d_binom;
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, bool>, std::unique_ptr<Plan>> plans;
   uint64_t epoch = 1;                                 // bumped whenever the planes are rebuilt
@@ -1593,25 +1617,29 @@ obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   obnsl_status st = set_device(d->device);
   if (st != OBNSL_OK) return st;
-  DevBuf<unsigned long long>& key = d->best_key;
-  DevBuf<unsigned long long>& id = d->best_id;
-  HIP_TRY(key.ensure(d->n));
-  HIP_TRY(id.ensure(d->n));
-  const uint32_t gb = (d->n + 255) / 256;
-  hipLaunchKernelGGL(fill_u64_kernel, dim3(gb), dim3(256), 0, d->stream, key.p, 0ull, d->n);
-  hipLaunchKernelGGL(fill_u64_kernel, dim3(gb), dim3(256), 0, d->stream, id.p, ~0ull, d->n);
+  DevBuf<unsigned long long>& buf = d->best_key;  // keys [0, n), ids [n, 2n)
+  HIP_TRY(buf.ensure(2 * (size_t)d->n));
+  unsigned long long* key = buf.p;
+  unsigned long long* id = buf.p + d->n;
+  hipLaunchKernelGGL(best_init_kernel, dim3((d->n + 255) / 256), dim3(256), 0, d->stream, key, id, d->n);
+  BestArgs args;
+  std::memset(&args, 0, sizeof(args));
+  args.kmax = max_parents + 1;
+  for (uint32_t k = 1; k <= max_parents + 1; ++k) {
+    const uint64_t nsub = binom_host(d->n, k);
+    args.scores[k - 1] = d_scores[k - 1];
+    args.nsubsets[k - 1] = nsub;
+    args.block_start[k] = args.block_start[k - 1] + (uint32_t)std::min<uint64_t>((nsub + 255) / 256, 512);
+  }
   for (int pass = 0; pass < 2; ++pass)
-    for (uint32_t k = 1; k <= max_parents + 1; ++k) {
-      const uint64_t nsub = binom_host(d->n, k);
-      const uint32_t bgrid = (uint32_t)std::min<uint64_t>((nsub + 255) / 256, 512);
-      hipLaunchKernelGGL(best_parents_kernel, dim3(bgrid), dim3(256), 0,
-                         d->stream, d_scores[k - 1], nsub, k, d->n, d->d_binom.p, key.p, id.p, pass);
-    }
+    hipLaunchKernelGGL(best_parents_kernel, dim3(args.block_start[max_parents + 1]), dim3(256), 0,
+                       d->stream, args, d->n, d->d_binom.p, key, id, pass);
   HIP_TRY(hipGetLastError());
-  std::vector<unsigned long long> hk(d->n), hi(d->n);
-  HIP_TRY(hipMemcpyAsync(hk.data(), key.p, d->n * 8, hipMemcpyDeviceToHost, d->stream));
-  HIP_TRY(hipMemcpyAsync(hi.data(), id.p, d->n * 8, hipMemcpyDeviceToHost, d->stream));
+  std::vector<unsigned long long> hboth(2 * (size_t)d->n);
+  HIP_TRY(hipMemcpyAsync(hboth.data(), buf.p, hboth.size() * 8, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
+  const unsigned long long* hk = hboth.data();
+  const unsigned long long* hi = hboth.data() + d->n;
   for (uint32_t v = 0; v < d->n; ++v) {
     if (hk[v] == 0) {  // nothing scored for this node in this shard
       best_score[v] = -INFINITY;
