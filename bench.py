@@ -79,7 +79,7 @@ def cpu_baseline(codes, card, names, max_parents, budget_s=20.0):
                "sample": f"{sc.shape[0]} size-{sc.shape[1]} subsets over 6 columns, all rows, oracle.c, {secs:.1f} s"}
     # the same restatement spread over every host core the box gives us
     threads = min(oracle.lib.oracle_max_threads(), 16)
-    wide = sorted(rng.choice(n, size=min(n, 12), replace=False).tolist())
+    wide = sorted(rng.choice(n, size=min(n, 20), replace=False).tolist())
     sub_codes = np.ascontiguousarray(codes[wide])
     t0 = time.perf_counter()
     sc = oracle.score_all(sub_codes, card[wide], min(k, len(wide)), nthreads=threads)
@@ -168,6 +168,18 @@ def main():
     alg_bytes_per_launch = top_scores_rank * N / launches_per_step
     achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
 
+    # HBM traffic of that kernel: not measurable from inside this process (PMC
+    # counters need a rocprofv3 pass); taken from the committed pass over this
+    # same command when the workload matches, else null
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc_path) and world == 1:
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        if pmc.get("workload") == args.workload:
+            traffic = pmc["traffic_bytes_per_launch"] / 1e9
+            traffic_src = "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, GB per launch)"
+
     out = {
         "metric": "parent-set scores/sec",
         "value": value,
@@ -185,7 +197,9 @@ def main():
                    "max_parents": mp, "score": spec["score"], "scores_per_step": int(n_scores),
                    "sharding": f"subsets split over {world} rank(s) by cost; per-node bests all-gathered"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                     "traffic_unit": "GB per launch (compare with algorithmic_bytes_per_launch)",
+                     "traffic_source": traffic_src,
                      "kernel": f"bitgemm_kernel (subset size {k_top})",
                      "kernel_ms": kernel_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch},
