@@ -28,6 +28,10 @@ WORKLOADS = {
     "hepar70_1e7_bdeu_mp3": dict(gen="hepar2", N=10_000_000, max_parents=3, score="bdeu"),
     "uniform128x4_1e7_bdeu_mp3": dict(gen="uniform128", N=10_000_000, max_parents=3, score="bdeu"),
     "asia8_1e5_bdeu_mp2": dict(gen="asia", N=100_000, max_parents=2, score="bdeu"),
+    # development probes for the path-selection threshold
+    "uniform20x6_1e6_bdeu_mp3": dict(gen="uniform20x6", N=1_000_000, max_parents=3, score="bdeu"),
+    "uniform20x5_1e6_bdeu_mp3": dict(gen="uniform20x5", N=1_000_000, max_parents=3, score="bdeu"),
+    "uniform20x8_1e6_bdeu_mp3": dict(gen="uniform20x8", N=1_000_000, max_parents=3, score="bdeu"),
 }
 HBM_PEAK_GBS = 8000.0
 
@@ -40,6 +44,8 @@ def make_data(spec):
         return synth.hepar2_shaped(spec["N"], seed=0)
     if spec["gen"] == "uniform128":
         return synth.uniform(128, 4, spec["N"], seed=0)
+    if spec["gen"].startswith("uniform20x"):
+        return synth.uniform(20, int(spec["gen"][len("uniform20x"):]), spec["N"], seed=0)
     if spec["gen"] == "asia":
         return synth.asia(spec["N"], seed=0)
     raise ValueError(spec["gen"])

@@ -627,6 +627,82 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
   }
 }
 
+// ------------------------------------------------------------------ histogram path
+// Tables too large for the bit-plane form (its cost grows with the number of
+// cells): the reference's own loop (include/base/contingency_table.h:52-55), one
+// workgroup per (table, row chunk).  Each lane reads 16 consecutive rows of every
+// column of the subset as one 16-byte load (coalesced, column-major), forms the
+// mixed-radix keys in registers and counts them in an LDS histogram; the chunk's
+// histogram is then added to the table's dense counters.  HBM/L2-bound: k bytes
+// per row per table.
+__device__ __forceinline__ uint32_t unrank_step(const uint64_t* __restrict__ binom, uint32_t n,
+                                                uint32_t j, uint64_t rank);
+constexpr uint32_t HIST_LDS_CELLS = 16384;   // 64 KiB of LDS counters
+constexpr uint32_t HIST_ROWS_PER_ITER = 256 * 16;
+__global__ __launch_bounds__(256) void count_hist_kernel(
+    const uint8_t* __restrict__ codes, uint64_t stride, uint64_t num_rows, uint32_t n,
+    const uint32_t* __restrict__ card, const uint64_t* __restrict__ binom, uint32_t k,
+    uint64_t rank0, uint32_t nchunks, uint64_t rows_per_chunk,
+    const uint64_t* __restrict__ tbl_off, uint32_t* __restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+  const uint32_t table = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+  // subset of this table from its colex rank
+  uint32_t vars[KMAX], wgt[KMAX];
+  {
+    uint64_t rem = rank0 + table;
+#pragma unroll
+    for (int j = KMAX; j >= 1; --j) {
+      vars[j - 1] = 0;
+      if (j > (int)k) continue;
+      const uint32_t v = unrank_step(binom, n, (uint32_t)j, rem);
+      vars[j - 1] = v;
+      rem -= binom[v * (KMAX + 1) + j];
+    }
+  }
+  uint32_t cells = 1;
+#pragma unroll
+  for (int i = KMAX - 1; i >= 0; --i) {
+    wgt[i] = 0;
+    if (i >= (int)k) continue;
+    wgt[i] = cells;  // the last variable has weight 1
+    cells *= card[vars[i]];
+  }
+  const bool use_lds = cells <= HIST_LDS_CELLS;
+  uint32_t* dst = counts + tbl_off[table];
+  if (use_lds) {
+    for (uint32_t c = threadIdx.x; c < cells; c += 256) hist[c] = 0;
+    __syncthreads();
+  }
+  const uint64_t r0 = (uint64_t)chunk * rows_per_chunk;
+  const uint64_t r1 = min(r0 + rows_per_chunk, num_rows);
+  for (uint64_t base = r0 + (uint64_t)threadIdx.x * 16; base < r1; base += HIST_ROWS_PER_ITER) {
+    uint32_t key[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) key[b] = 0;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      if (i >= (int)k) continue;
+      const uint4 x = *reinterpret_cast<const uint4*>(codes + (size_t)vars[i] * stride + base);
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int b = 0; b < 16; ++b) key[b] += ((xs[b >> 2] >> (8 * (b & 3))) & 0xffu) * wgt[i];
+    }
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      if (base + b >= r1) continue;
+      if (use_lds) atomicAdd(&hist[key[b]], 1u);
+      else atomicAdd(&dst[key[b]], 1u);
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < cells; c += 256) {
+      const uint32_t v = hist[c];
+      if (v) atomicAdd(&dst[c], v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ best parents
 __device__ __forceinline__ uint64_t ordered_key(double x) {
   const uint64_t b = (uint64_t)__double_as_longlong(x);
@@ -778,6 +854,13 @@ struct Batch {
   uint64_t ntables = 0, ncells = 0;
 };
 
+struct HistBatch {    // histogram path: a run of consecutive ranks whose dense tables fit one buffer
+  uint64_t rank0 = 0, cells_total = 0;
+  uint32_t ntables = 0, max_cells = 1;
+  DevBuf<uint64_t> off;     // first counter of each table
+  DevBuf<TableDesc> tds;
+};
+
 struct Plan {
   uint32_t k = 0, kr = 0, kc = 0;
   bool reduced = false;         // rows/columns cover states 1..r-1 only (see score_reduced_kernel)
@@ -811,6 +894,7 @@ struct obnsl_data {
   DevBuf<unsigned long long> best_key;           // per-node arg-max scratch of obnsl_best_parents
   DevBuf<uint64_t> d_binom;
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, bool>, std::unique_ptr<Plan>> plans;
+  std::map<std::tuple<uint32_t, uint64_t, uint64_t>, std::vector<std::unique_ptr<HistBatch>>> hist_plans;
   uint64_t epoch = 1;                                 // bumped whenever the planes are rebuilt
   hipStream_t side = nullptr;                         // second stream for obnsl_precount (default priority)
   hipEvent_t side_fork = nullptr, side_join = nullptr;
@@ -1179,6 +1263,86 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
   return OBNSL_OK;
 }
 
+// Histogram path for the size-k subsets with colex ranks [lo, hi): batches of
+// tables, each batch = zero the dense counters, one count_hist_kernel launch,
+// one score_tables_kernel launch.
+obnsl_status run_hist_range(obnsl_data* d, uint32_t k, uint64_t lo, uint64_t hi,
+                            obnsl_score_kind kind, double ess, double* d_scores) {
+  const uint64_t cell_budget = 1ull << 28;  // counters per batch (1 GiB)
+  auto key = std::make_tuple(k, lo, hi);
+  auto it = d->hist_plans.find(key);
+  if (it == d->hist_plans.end()) {
+    // table descriptors of the range, cut into batches (built once, kept)
+    std::vector<std::unique_ptr<HistBatch>> batches;
+    std::vector<uint32_t> vars(k);
+    uint64_t t = lo;
+    while (t < hi) {
+      auto hb = std::make_unique<HistBatch>();
+      std::vector<uint64_t> off;
+      std::vector<TableDesc> tds;
+      hb->rank0 = t;
+      while (t < hi && tds.size() < (1u << 22)) {
+        obnsl_status st = obnsl_unrank(t, k, vars.data());
+        if (st != OBNSL_OK) return st;
+        TableDesc td;
+        std::memset(&td, 0, sizeof(td));
+        td.k = k;
+        uint64_t cells = 1;
+        for (uint32_t i = 0; i < k; ++i) {
+          td.cards[i] = d->card[vars[i]];
+          cells *= d->card[vars[i]];
+          if (cells > (1ull << 26)) return fail(OBNSL_ERR_UNSUPPORTED, "table has more than 2^26 cells");
+        }
+        if (!tds.empty() && hb->cells_total + cells > cell_budget) break;
+        td.off = hb->cells_total;
+        off.push_back(hb->cells_total);
+        tds.push_back(td);
+        hb->cells_total += cells;
+        hb->max_cells = std::max<uint32_t>(hb->max_cells, (uint32_t)cells);
+        ++t;
+      }
+      hb->ntables = (uint32_t)tds.size();
+      HIP_TRY(hb->off.upload(off));
+      HIP_TRY(hb->tds.upload(tds));
+      batches.push_back(std::move(hb));
+    }
+    it = d->hist_plans.emplace(key, std::move(batches)).first;
+  }
+  for (auto& hbp : it->second) {
+    HistBatch* hb = hbp.get();
+    const uint32_t nt = hb->ntables;
+    if (nt == 0) continue;
+    HIP_TRY(d->counts.ensure(hb->cells_total));
+    HIP_TRY(hipMemsetAsync(d->counts.p, 0, hb->cells_total * sizeof(uint32_t), d->stream));
+    // enough workgroups to fill the chip, chunks a multiple of one iteration's rows
+    uint64_t nchunks = std::max<uint64_t>(1, std::min<uint64_t>(4096 / nt + 1,
+                                                                (d->N + HIST_ROWS_PER_ITER - 1) / HIST_ROWS_PER_ITER));
+    uint64_t rpc = (d->N + nchunks - 1) / nchunks;
+    rpc = (rpc + HIST_ROWS_PER_ITER - 1) / HIST_ROWS_PER_ITER * HIST_ROWS_PER_ITER;
+    nchunks = (d->N + rpc - 1) / rpc;
+    const size_t lds = (size_t)std::min<uint32_t>(hb->max_cells, HIST_LDS_CELLS) * sizeof(uint32_t);
+    if (d->ev_used == d->ev.size()) {
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      d->ev.push_back({e0, e1});
+      d->ev_size.push_back(0);
+    }
+    d->ev_size[d->ev_used] = k;
+    auto& ev = d->ev[d->ev_used++];
+    HIP_TRY(hipEventRecord(ev.first, d->stream));
+    hipLaunchKernelGGL(count_hist_kernel, dim3(nt * (uint32_t)nchunks), dim3(256), lds, d->stream,
+                       d->codes.p, d->stride, d->N, d->n, d->d_card.p, d->d_binom.p, k, hb->rank0,
+                       (uint32_t)nchunks, rpc, hb->off.p, d->counts.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, d->stream));
+    hipLaunchKernelGGL(score_tables_kernel, dim3((nt + 3) / 4), dim3(256), 0, d->stream, d->counts.p,
+                       hb->tds.p, (uint64_t)nt, (int)kind, ess, d_scores + hb->rank0 * k);
+    HIP_TRY(hipGetLastError());
+  }
+  return OBNSL_OK;
+}
+
 obnsl_status check_kind(obnsl_score_kind kind) {
   if (kind == OBNSL_SCORE_BDEU || kind == OBNSL_SCORE_BIC) return OBNSL_OK;
   return fail(OBNSL_ERR_UNSUPPORTED, "Unsupported score type.");
@@ -1431,7 +1595,21 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
   uint64_t max_cells = 1;
   for (uint32_t i = 0; i < k; ++i) max_cells *= sorted_card[i];
   static const bool allow_reduced = std::getenv("OBNSL_NO_REDUCED") == nullptr;
-  if (allow_reduced && max_cells <= REDUCED_MAX_CELLS) {
+  static const bool force_hist = std::getenv("OBNSL_FORCE_HIST") != nullptr;
+  bool use_reduced = allow_reduced && max_cells <= REDUCED_MAX_CELLS && !force_hist;
+  if (use_reduced && std::getenv("OBNSL_FORCE_BITGEMM") == nullptr) {
+    // The bit-plane form costs ~ (reduced cells) x (32-row words); the per-row
+    // histogram costs ~ (tables) x (rows).  Measured on MI355X: 6.7e-5 ns per
+    // cell-word (at ~80 % tile fill) against 4.5e-4 ns per table-row, i.e. the
+    // histogram wins above ~215 reduced cells per table.
+    Plan* full = nullptr;
+    st = build_plan(d, k, 0, 1, true, &full);
+    if (st != OBNSL_OK) return st;
+    const double est_bit = (double)full->batches[0]->ncells * (double)d->wp * 6.7e-5;
+    const double est_hist = (double)nsub * (double)d->N * 4.5e-4;
+    if (est_hist < est_bit) use_reduced = false;
+  }
+  if (use_reduced) {
     ReducedViews views;
     std::memset(&views, 0, sizeof(views));
     Plan* own = nullptr;     // lists this shard's tables
@@ -1479,6 +1657,12 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
       gprev = prev->G.p;
     }
     st = run_functional(d, own, views, k, max_cells, kind, ess, gprev, g0, d_scores);
+    if (st != OBNSL_OK) return st;
+  } else if (std::getenv("OBNSL_FORCE_BITGEMM") == nullptr) {
+    // large tables: per-row LDS histograms over this shard's contiguous rank range
+    const uint64_t lo = nsub / num_shards * shard + std::min<uint64_t>(shard, nsub % num_shards);
+    const uint64_t hi = nsub / num_shards * (shard + 1) + std::min<uint64_t>(shard + 1, nsub % num_shards);
+    st = run_hist_range(d, k, lo, hi, kind, ess, d_scores);
     if (st != OBNSL_OK) return st;
   } else {
     Plan* plan = nullptr;

@@ -226,3 +226,34 @@ def test_alarm_shape_full_size_properties(engine):
             want = [oracle.local_score(ocnt, card[subs[t]], ci) for ci in range(k)]
             assert rel_err(have[t], want) <= REL
     d.close()
+
+
+def test_high_cardinality_tables_use_the_histogram_path(engine):
+    """Tables above 4096 cells are counted by per-row LDS histograms (and, above
+    16384 cells, by global atomics): same bars as everywhere else."""
+    torch = pytest.importorskip("torch")
+    import oracle
+    from openbnsl_amd import synth
+    cards = [12, 9, 7, 11, 5, 8, 3]
+    codes, card, _, _ = synth.random_bn(cards, 20_003, seed=12, min_prob=0.01)
+    d = engine.Data(codes, card)
+    for k in (3, 4, 5):          # 1188 (bit-plane path), 9504 (LDS histogram), 66528 cells (global)
+        want = oracle.score_all(codes, card, k, nthreads=4)
+        have = d.score_all(k)
+        assert rel_err(have, want) <= REL, k
+    k = 4
+    T = d.num_subsets(k)
+    parts = []
+    for sh in range(3):
+        buf = torch.full((T * k,), float("-inf"), dtype=torch.float64, device="cuda")
+        d.score_all_device(k, buf.data_ptr(), shard=sh, num_shards=3)
+        torch.cuda.synchronize()
+        parts.append(buf)
+    stack = torch.stack(parts)
+    assert int((stack > float("-inf")).sum(dim=0).min()) == 1
+    assert int((stack > float("-inf")).sum(dim=0).max()) == 1
+    want = oracle.score_all(codes, card, k, nthreads=4)
+    assert rel_err(stack.max(dim=0).values.cpu().numpy().reshape(T, k), want) <= REL
+    vs = [0, 1, 3, 5]
+    assert np.array_equal(d.count(vs), oracle.count(codes, card, vs))
+    d.close()
