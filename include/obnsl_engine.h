@@ -138,6 +138,14 @@ obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
                                 uint32_t max_parents, double* best_score,
                                 uint32_t* best_size, uint64_t* best_rank);
 
+/* The same reduction left on the device and asynchronous on the data set's
+ * stream: d_out (device, 3 * num_vars doubles) receives, per node, the best
+ * score, the number of parents and the colex rank of the parent set (integers
+ * stored exactly as doubles; -inf, 0, 0 for a node this shard has no score for).
+ * This is the record that ranks all-gather. */
+obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_scores,
+                                       uint32_t max_parents, double* d_out);
+
 /* colex rank <-> subset helpers (host, no GPU). */
 uint64_t obnsl_binomial(uint32_t n, uint32_t k);
 obnsl_status obnsl_unrank(uint64_t rank, uint32_t k, uint32_t* var_ids_out);

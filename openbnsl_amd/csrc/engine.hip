@@ -810,6 +810,25 @@ __global__ void best_init_kernel(unsigned long long* keys, unsigned long long* i
   }
 }
 
+// (ordered key, id) -> (score, number of parents, colex rank of the parent set) as doubles
+__global__ void best_decode_kernel(const unsigned long long* __restrict__ keys,
+                                   const unsigned long long* __restrict__ ids, uint32_t n,
+                                   double* __restrict__ out) {
+  const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= n) return;
+  const unsigned long long kb = keys[v];
+  if (kb == 0) {  // nothing scored for this node in this shard
+    out[3 * v] = -INFINITY;
+    out[3 * v + 1] = 0.0;
+    out[3 * v + 2] = 0.0;
+    return;
+  }
+  const unsigned long long bits = (kb >> 63) ? (kb & 0x7fffffffffffffffull) : ~kb;
+  out[3 * v] = __longlong_as_double((long long)bits);
+  out[3 * v + 1] = (double)(ids[v] >> 56);
+  out[3 * v + 2] = (double)(ids[v] & ((1ull << 56) - 1));
+}
+
 // ------------------------------------------------------------------ host side
 uint64_t binom_host(uint32_t n, uint32_t k) {
   if (k > n) return 0;
@@ -1152,8 +1171,9 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
   return OBNSL_OK;
 }
 
-// Folds the event pairs of the previous obnsl_score_all into the running
-// per-subset-size totals (waits for them if they are still in flight).
+// Folds the event pairs recorded since the last call into the running
+// per-subset-size totals (waits for them if they are still in flight).  Only
+// obnsl_kernel_time calls this, so scoring calls never block on the device.
 obnsl_status resolve_events(obnsl_data* d) {
   for (uint32_t i = 0; i < d->ev_used; ++i) {
     float t = 0;
@@ -1197,6 +1217,10 @@ obnsl_status launch_count(obnsl_data* d, const Plan* plan, const Batch* b, uint3
   ksplit = (steps_total + sps - 1) / sps;
   const int atomics = ksplit > 1;
   if (atomics) HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
+  if (d->ev_used >= 4096) {  // bound the pool: fold what has been recorded so far
+    obnsl_status st = resolve_events(d);
+    if (st != OBNSL_OK) return st;
+  }
   if (d->ev_used == d->ev.size()) {
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -1584,8 +1608,6 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
     HIP_TRY(tmp.ensure(nsub * k));
     d_scores = tmp.p;
   }
-  st = resolve_events(d);
-  if (st != OBNSL_OK) return st;
 
   // Reduced mode (count only states 1..r-1, expand in the scorer) whenever the
   // largest full table of this size fits the scorer's LDS; otherwise every state
@@ -1701,8 +1723,6 @@ obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32
   uint64_t max_cells = 1;
   for (uint32_t i = 0; i < kmax; ++i) max_cells *= sorted_card[i];
   if (std::getenv("OBNSL_NO_REDUCED") || max_cells > REDUCED_MAX_CELLS) return OBNSL_OK;  // nothing to share
-  st = resolve_events(d);
-  if (st != OBNSL_OK) return st;
   if (!d->side) {
     HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&d->side_fork, hipEventDisableTiming));
@@ -1792,11 +1812,8 @@ obnsl_status obnsl_score_subsets(obnsl_data* d, obnsl_score_kind kind, double es
   return OBNSL_OK;
 }
 
-obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
-                                uint32_t max_parents, double* best_score,
-                                uint32_t* best_size, uint64_t* best_rank) {
-  if (!d || !d_scores || !best_score || !best_size || !best_rank)
-    return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+static obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_scores,
+                                       uint32_t max_parents) {
   if (max_parents + 1 > (uint32_t)KMAX || max_parents + 1 > d->n)
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   obnsl_status st = set_device(d->device);
@@ -1819,8 +1836,18 @@ obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
     hipLaunchKernelGGL(best_parents_kernel, dim3(args.block_start[max_parents + 1]), dim3(256), 0,
                        d->stream, args, d->n, d->d_binom.p, key, id, pass);
   HIP_TRY(hipGetLastError());
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
+                                uint32_t max_parents, double* best_score,
+                                uint32_t* best_size, uint64_t* best_rank) {
+  if (!d || !d_scores || !best_score || !best_size || !best_rank)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  obnsl_status st = queue_best_parents(d, d_scores, max_parents);
+  if (st != OBNSL_OK) return st;
   std::vector<unsigned long long> hboth(2 * (size_t)d->n);
-  HIP_TRY(hipMemcpyAsync(hboth.data(), buf.p, hboth.size() * 8, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipMemcpyAsync(hboth.data(), d->best_key.p, hboth.size() * 8, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
   const unsigned long long* hk = hboth.data();
   const unsigned long long* hi = hboth.data() + d->n;
@@ -1839,6 +1866,17 @@ obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
     best_size[v] = (uint32_t)(hi[v] >> 56);
     best_rank[v] = hi[v] & ((1ull << 56) - 1);
   }
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_scores,
+                                       uint32_t max_parents, double* d_out) {
+  if (!d || !d_scores || !d_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  obnsl_status st = queue_best_parents(d, d_scores, max_parents);
+  if (st != OBNSL_OK) return st;
+  hipLaunchKernelGGL(best_decode_kernel, dim3((d->n + 255) / 256), dim3(256), 0, d->stream,
+                     d->best_key.p, d->best_key.p + d->n, d->n, d_out);
+  HIP_TRY(hipGetLastError());
   return OBNSL_OK;
 }
 

@@ -24,6 +24,20 @@ def combine_best(parts):
     return sel[:, 0].copy(), sel[:, 1].astype(np.uint32), sel[:, 2].astype(np.uint64)
 
 
+def combine_best_device(parts):
+    """torch form of combine_best: parts [world, n, 3] (any device) -> [n, 3]."""
+    import torch
+    score = parts[:, :, 0]
+    best = score.max(dim=0).values
+    m = score == best
+    inf = torch.full_like(score, float("inf"))
+    size = torch.where(m, parts[:, :, 1], inf)
+    bsize = size.min(dim=0).values
+    m2 = m & (size == bsize)
+    brank = torch.where(m2, parts[:, :, 2], inf).min(dim=0).values
+    return torch.stack([best, bsize, brank], dim=1)
+
+
 def allgather_best(score, size, rank, device=None):
     """All-gathers this rank's per-node bests and returns the combined result.
     device: torch device of the exchange buffer (cuda for nccl, None/cpu for gloo)."""

@@ -46,6 +46,7 @@ SIGNATURES = {
                                            ctypes.c_uint32, ctypes.c_uint64, _f64p]),
     "obnsl_best_parents": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _f64p,
                                           _u32p, _u64p]),
+    "obnsl_best_parents_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _vp]),
     "obnsl_binomial": (ctypes.c_uint64, [ctypes.c_uint32, ctypes.c_uint32]),
     "obnsl_unrank": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, _u32p]),
     "obnsl_rank": (ctypes.c_uint64, [_u32p, ctypes.c_uint32]),
@@ -185,6 +186,11 @@ class Data:
         _check(lib.obnsl_best_parents(self._h, arr, max_parents, sc.ctypes.data_as(_f64p),
                                       sz.ctypes.data_as(_u32p), rk.ctypes.data_as(_u64p)))
         return sc, sz, rk
+
+    def best_parents_device(self, score_ptrs, max_parents, out_ptr):
+        """Asynchronous; out_ptr: device pointer to 3 * n doubles (score, size, rank per node)."""
+        arr = (_vp * len(score_ptrs))(*score_ptrs)
+        _check(lib.obnsl_best_parents_device(self._h, arr, max_parents, out_ptr))
 
     def kernel_time(self, k, reset=False):
         """(total ms, launches) of the size-k counting kernel since the last reset."""

@@ -31,22 +31,40 @@ class HotPath:
                        for k in range(1, max_parents + 2)]
         self.ptrs = [t.data_ptr() for t in self.tables]
         self.scores_per_pass = sum(self.data.num_subsets(k) * k for k in range(1, max_parents + 2))
+        self.best = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
+        self.gathered = (torch.empty((world, self.n, 3), dtype=torch.float64, device=self.dev)
+                         if world > 1 else None)
 
     def step(self):
-        """One pass; returns (best_score, best_size, best_rank) per node, combined
-        over all ranks when world > 1."""
+        """One pass, queued asynchronously on the current stream (no host
+        synchronisation when world == 1 or the backend is nccl).  Returns a device
+        tensor [n, 3]: per node the best score, the number of parents and the colex
+        rank of the parent set, combined over all ranks when world > 1."""
+        torch = self.torch
         d = self.data
         d.pack()
         d.precount(self.mp + 1, self.rank, self.world)
         for k in range(1, self.mp + 2):
             d.score_all_device(k, self.ptrs[k - 1], kind=self.kind, ess=self.ess,
                                shard=self.rank, num_shards=self.world)
-        sc, sz, rk = d.best_parents(self.ptrs, self.mp)
-        if self.world > 1:
-            import torch.distributed as dist
-            on_gpu = dist.get_backend() == "nccl"
-            sc, sz, rk = obd.allgather_best(sc, sz, rk, device=self.dev if on_gpu else None)
-        return sc, sz, rk
+        d.best_parents_device(self.ptrs, self.mp, self.best.data_ptr())
+        if self.world == 1:
+            return self.best
+        import torch.distributed as dist
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.best.view(-1))
+            return obd.combine_best_device(self.gathered)
+        # gloo: host tensors only
+        mine = self.best.cpu()
+        out = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype)
+        dist.all_gather_into_tensor(out.view(-1), mine.view(-1))
+        return obd.combine_best_device(out).to(self.dev)
+
+    @staticmethod
+    def to_host(best):
+        """(best_score, best_size, best_rank) numpy arrays from step()'s tensor."""
+        b = best.detach().cpu().numpy()
+        return b[:, 0].copy(), b[:, 1].astype(np.uint32), b[:, 2].astype(np.uint64)
 
     def shard_scores(self, k):
         """Number of finite entries this rank holds in the size-k table."""

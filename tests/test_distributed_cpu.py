@@ -74,3 +74,6 @@ def test_combine_best_tie_rules():
     assert sc.tolist() == [-5.0, -1.0, -2.0]
     assert sz.tolist() == [1, 1, 3]          # fewer parents wins the tie on node 0
     assert rk.tolist() == [9, 2, 1]          # lower rank wins the tie on node 1
+    import torch
+    t = obd.combine_best_device(torch.from_numpy(parts))
+    assert t.tolist() == [[-5.0, 1.0, 9.0], [-1.0, 1.0, 2.0], [-2.0, 3.0, 1.0]]

@@ -257,3 +257,24 @@ def test_high_cardinality_tables_use_the_histogram_path(engine):
     vs = [0, 1, 3, 5]
     assert np.array_equal(d.count(vs), oracle.count(codes, card, vs))
     d.close()
+
+
+def test_hot_path_device_result_matches_host_result(engine):
+    """The asynchronous pipeline (device-resident per-node bests) against the
+    synchronous obnsl_best_parents and a brute-force arg-max over oracle scores."""
+    import oracle
+    from openbnsl_amd import synth
+    from openbnsl_amd.pipeline import HotPath, best_parents_reference
+    codes, card, _, _ = synth.random_bn([2, 3, 4, 2, 3, 4, 3, 2, 4, 3], 12_000, seed=31)
+    hot = HotPath(codes, card, 3)
+    for _ in range(3):
+        dev = hot.step()
+    sc, sz, rk = hot.to_host(dev)
+    sc2, sz2, rk2 = hot.data.best_parents(hot.ptrs, 3)
+    assert np.array_equal(sc, sc2) and np.array_equal(sz, sz2) and np.array_equal(rk, rk2)
+    tables = [oracle.score_all(codes, card, k, nthreads=4) for k in range(1, 5)]
+    wsc, wsz, wrk = best_parents_reference(tables, 10)
+    assert rel_err(sc, wsc) <= REL and np.array_equal(sz, wsz) and np.array_equal(rk, wrk)
+    ms, launches = hot.data.kernel_time(4)
+    assert launches == 3 and ms > 0
+    hot.close()

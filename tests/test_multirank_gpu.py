@@ -24,7 +24,7 @@ def _worker(rank, world, port, q):
     hot = HotPath(codes, card, mp, rank=rank, world=world, device_index=0)
     got = None
     for _ in range(2):                       # second pass exercises the cached plans
-        got = hot.step()
+        got = hot.to_host(hot.step())
     mine = [hot.shard_scores(k) for k in range(1, mp + 2)]
     tables = [oracle.score_all(codes, card, k, nthreads=2) for k in range(1, mp + 2)]
     want = best_parents_reference(tables, len(card))
