@@ -1,51 +1,65 @@
-// Development microbenchmark: issue rate of v_and_b32 / v_bcnt_u32_b32 on gfx950.
+// Development microbenchmark: issue rate of single VALU instructions on gfx950
+// (inline asm, independent destination registers, 16 waves per CU).
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include <cstdlib>
+#define REP16(x) x x x x x x x x x x x x x x x x
 template <int MODE>
 __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t seed) {
-  uint32_t a[16], acc[16];
-  for (int i = 0; i < 16; ++i) { a[i] = seed * (threadIdx.x + 1 + i); acc[i] = i; }
-  uint32_t b = seed ^ threadIdx.x;
+  uint32_t a = seed * (threadIdx.x + 1), b = seed ^ threadIdx.x;
+  uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
   for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (MODE == 0) acc[i] = (acc[i] & a[i]) + 0;            // v_and only (dependent per acc, 16 chains)
-        if (MODE == 1) acc[i] += __popc(a[i]);                  // v_bcnt accumulate
-        if (MODE == 2) acc[i] += __popc(a[i] & b);              // and + bcnt
-        if (MODE == 3) acc[i] = acc[i] * 3 + a[i];              // v_mad_u32_u24-ish / mul-add
-      }
-      b = b * 1664525u + 1013904223u;
-      if (MODE != 2) { for (int i = 0; i < 16; ++i) a[i] ^= b; }
-    }
+    if (MODE == 0)
+      { REP16(asm volatile("v_and_b32 %0, %8, %9\n v_and_b32 %1, %8, %9\n v_and_b32 %2, %8, %9\n v_and_b32 %3, %8, %9\n"
+                         "v_and_b32 %4, %8, %9\n v_and_b32 %5, %8, %9\n v_and_b32 %6, %8, %9\n v_and_b32 %7, %8, %9\n"
+                         : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7) : "v"(a), "v"(b));) }
+    if (MODE == 1)
+      { REP16(asm volatile("v_bcnt_u32_b32 %0, %8, %0\n v_bcnt_u32_b32 %1, %8, %1\n v_bcnt_u32_b32 %2, %8, %2\n v_bcnt_u32_b32 %3, %8, %3\n"
+                         "v_bcnt_u32_b32 %4, %8, %4\n v_bcnt_u32_b32 %5, %8, %5\n v_bcnt_u32_b32 %6, %8, %6\n v_bcnt_u32_b32 %7, %8, %7\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b));) }
+    if (MODE == 2)
+      { REP16(asm volatile("v_add_u32 %0, %8, %0\n v_add_u32 %1, %8, %1\n v_add_u32 %2, %8, %2\n v_add_u32 %3, %8, %3\n"
+                         "v_add_u32 %4, %8, %4\n v_add_u32 %5, %8, %5\n v_add_u32 %6, %8, %6\n v_add_u32 %7, %8, %7\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b));) }
+    if (MODE == 3)
+      { REP16(asm volatile("v_mbcnt_lo_u32_b32 %0, %8, %0\n v_mbcnt_lo_u32_b32 %1, %8, %1\n v_mbcnt_lo_u32_b32 %2, %8, %2\n v_mbcnt_lo_u32_b32 %3, %8, %3\n"
+                         "v_mbcnt_lo_u32_b32 %4, %8, %4\n v_mbcnt_lo_u32_b32 %5, %8, %5\n v_mbcnt_lo_u32_b32 %6, %8, %6\n v_mbcnt_lo_u32_b32 %7, %8, %7\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b));) }
+    if (MODE == 4)
+      { REP16(asm volatile("v_and_b32 %0, %8, %9\n v_bcnt_u32_b32 %1, %0, %1\n v_and_b32 %2, %8, %9\n v_bcnt_u32_b32 %3, %2, %3\n"
+                         "v_and_b32 %4, %8, %9\n v_bcnt_u32_b32 %5, %4, %5\n v_and_b32 %6, %8, %9\n v_bcnt_u32_b32 %7, %6, %7\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b));) }
+    if (MODE == 5)
+      { REP16(asm volatile("v_sad_u32 %0, %8, %9, %0\n v_sad_u32 %1, %8, %9, %1\n v_sad_u32 %2, %8, %9, %2\n v_sad_u32 %3, %8, %9, %3\n"
+                         "v_sad_u32 %4, %8, %9, %4\n v_sad_u32 %5, %8, %9, %5\n v_sad_u32 %6, %8, %9, %6\n v_sad_u32 %7, %8, %9, %7\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b));) }
   }
-  uint32_t s = 0;
-  for (int i = 0; i < 16; ++i) s += acc[i];
-  out[blockIdx.x * 256 + threadIdx.x] = s;
+  out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
 }
-template <int MODE> void run(const char* name, int ops_per_inner) {
-  uint32_t* d; hipMalloc(&d, 256 * 8 * 256 * 4);
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const int iters = 20000;
-  for (int wpc : {4, 8, 16}) {   // waves per CU via blocks of 256 threads: blocks = 256 CUs * wpc/4
+template <int MODE> void run(const char* name) {
+  uint32_t* d; (void)hipMalloc(&d, 256 * 8 * 256 * 4);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int iters = 4000;
+  for (int wpc : {4, 8, 16}) {
     int blocks = 256 * wpc / 4;
     hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 100, 12345u);
-    hipEventRecord(e0);
+    (void)hipEventRecord(e0);
     hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 12345u);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    double winstr = (double)blocks * 4 * iters * 4 * 16 * ops_per_inner;
-    printf("%s waves/CU=%d: %.3f ms, %.2f wave-instr/cycle/CU @2.4GHz (counted ops only)\n", name, wpc, ms,
-           winstr / (ms * 1e-3) / 256 / 2.4e9);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    double winstr = (double)blocks * 4 * iters * 128;
+    double per_simd_ns = ms * 1e6 / ((double)wpc / 4 * iters * 128);   // ns per wave-instruction per SIMD
+    printf("%-10s waves/CU=%2d: %.3f ms  %.2f ns per wave-instr per SIMD  (%.2f cycles @2.4GHz, %.2f @2.0GHz)\n", name, wpc, ms,
+           per_simd_ns, per_simd_ns * 2.4, per_simd_ns * 2.0);
+    (void)winstr;
   }
-  hipFree(d);
+  (void)hipFree(d);
 }
 int main() {
-  run<0>("and", 1);
-  run<1>("bcnt", 1);
-  run<2>("and+bcnt", 2);
-  run<3>("mad", 1);
+  run<0>("v_and");
+  run<2>("v_add");
+  run<1>("v_bcnt");
+  run<3>("v_mbcnt_lo");
+  run<5>("v_sad_u32");
+  run<4>("and+bcnt");
   return 0;
 }
