@@ -146,6 +146,19 @@ obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
 obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_scores,
                                        uint32_t max_parents, double* d_out);
 
+/* Replaces exhaustive_search(df, score_type, max_parents, is_deterministic)
+ * (src/structure_learning/exhaustive_search.cpp:14-165) end to end on the
+ * device: the score tables of sizes 1..max_parents+1, then the subset dynamic
+ * program (one launch per subset size, the reference's tie rules) and the
+ * back-track.  parents_out[v] (host, num_vars entries) = bitmask of the parents
+ * of v in the optimal DAG; total_score_out (may be null) = its score.
+ * Errors as the reference: max_parents > num_vars-1 and num_vars > 64 are
+ * OBNSL_ERR_INVALID_ARGUMENT with its messages; so is a problem whose n * 2^n
+ * tables do not fit the device (the reference cannot run those either). */
+obnsl_status obnsl_exhaustive_search(obnsl_data* d, obnsl_score_kind kind, double ess,
+                                     uint32_t max_parents, uint64_t* parents_out,
+                                     double* total_score_out);
+
 /* colex rank <-> subset helpers (host, no GPU). */
 uint64_t obnsl_binomial(uint32_t n, uint32_t k);
 obnsl_status obnsl_unrank(uint64_t rank, uint32_t k, uint32_t* var_ids_out);

@@ -829,6 +829,96 @@ __global__ void best_decode_kernel(const unsigned long long* __restrict__ keys,
   out[3 * v + 2] = (double)(ids[v] & ((1ull << 56) - 1));
 }
 
+// ------------------------------------------------------------------ subset DP
+// The dynamic program of exhaustive_search
+// (src/structure_learning/exhaustive_search.cpp:47-148), one launch per subset
+// size: all subsets of one size are independent (they read only entries of
+// strictly smaller subsets), so each thread handles one mask S.
+//   best-parent table (:75-87): start from the score of the full candidate set
+//   (or -inf beyond max_parents); a sub-table entry replaces it when >= (ties go
+//   to the smaller set, later parents override earlier ones);
+//   best sink (:89-94): strict >, first child wins ties, 0 = uninitialised.
+// bls/bps hold, per child c, the 2^(n-1) masks that do not contain c.
+struct DpScores {
+  const double* tbl[KMAX];  // tbl[k-1][rank * k + i]
+  uint32_t max_scored;      // max_parents + 1
+};
+__device__ __forceinline__ uint64_t dp_squeeze(uint64_t mask, uint32_t c) {  // drop bit position c
+  return (mask & ((1ull << c) - 1)) | ((mask >> (c + 1)) << c);
+}
+__global__ __launch_bounds__(256) void dp_level_kernel(
+    uint32_t n, uint32_t level, DpScores sc, const uint64_t* __restrict__ binom,
+    double* __restrict__ best_gs, signed char* __restrict__ best_ch, double* __restrict__ bls,
+    uint32_t* __restrict__ bps) {
+  const uint64_t combs = 1ull << n, half = combs >> 1;
+  for (uint64_t S = (uint64_t)blockIdx.x * 256 + threadIdx.x; S < combs;
+       S += (uint64_t)gridDim.x * 256) {
+    if ((uint32_t)__popcll(S) != level) continue;
+    const bool scored = level <= sc.max_scored;
+    const double* row = nullptr;
+    if (scored) {
+      uint64_t rank = 0;
+      uint32_t j = 0;
+      for (uint64_t m = S; m; m &= m - 1) {
+        ++j;
+        rank += binom[(uint32_t)(__ffsll((long long)m) - 1) * (KMAX + 1) + j];
+      }
+      const double* base = nullptr;
+#pragma unroll
+      for (int q = 0; q < KMAX; ++q)
+        if ((uint32_t)q + 1 == level) base = sc.tbl[q];
+      row = base + rank * level;
+    }
+    double bgs = 0.0;
+    int bch = -1;
+    uint32_t ci = 0;
+    for (uint64_t mc = S; mc; mc &= mc - 1, ++ci) {
+      const uint32_t child = (uint32_t)(__ffsll((long long)mc) - 1);
+      const uint64_t P = S & ~(1ull << child);
+      double best = scored ? row[ci] : -INFINITY;
+      uint64_t best_ps = P;
+      for (uint64_t mp = P; mp; mp &= mp - 1) {
+        const uint32_t pv = (uint32_t)(__ffsll((long long)mp) - 1);
+        const uint64_t sub = dp_squeeze(P & ~(1ull << pv), child);
+        const double l = bls[child * half + sub];
+        if (l >= best) {
+          best = l;
+          best_ps = bps[child * half + sub];
+        }
+      }
+      const uint64_t slot = child * half + dp_squeeze(P, child);
+      bls[slot] = best;
+      bps[slot] = (uint32_t)best_ps;
+      const double gs = best_gs[P] + best;
+      if (bgs >= 0 || gs > bgs) {
+        bgs = gs;
+        bch = (int)child;
+      }
+    }
+    best_gs[S] = bgs;
+    best_ch[S] = (signed char)bch;
+  }
+}
+
+// Peels sinks off the full set (:132-148): parents[ch] = best parent set of ch
+// within the remaining variables.
+__global__ void dp_backtrack_kernel(uint32_t n, const double* __restrict__ best_gs,
+                                    const signed char* __restrict__ best_ch,
+                                    const uint32_t* __restrict__ bps, uint64_t* __restrict__ parents,
+                                    double* __restrict__ total) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint64_t combs = 1ull << n, half = combs >> 1;
+  uint64_t S = combs - 1;
+  total[0] = best_gs[S];
+  for (uint32_t v = 0; v < n; ++v) parents[v] = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t ch = (uint32_t)best_ch[S];
+    const uint64_t P = S & ~(1ull << ch);
+    parents[ch] = bps[ch * half + dp_squeeze(P, ch)];
+    S = P;
+  }
+}
+
 // ------------------------------------------------------------------ host side
 uint64_t binom_host(uint32_t n, uint32_t k) {
   if (k > n) return 0;
@@ -1877,6 +1967,74 @@ obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_sco
   hipLaunchKernelGGL(best_decode_kernel, dim3((d->n + 255) / 256), dim3(256), 0, d->stream,
                      d->best_key.p, d->best_key.p + d->n, d->n, d_out);
   HIP_TRY(hipGetLastError());
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_exhaustive_search(obnsl_data* d, obnsl_score_kind kind, double ess,
+                                     uint32_t max_parents, uint64_t* parents_out,
+                                     double* total_score_out) {
+  if (!d || !parents_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  const uint32_t n = d->n;
+  // reference: exhaustive_search.cpp:18-23
+  if (max_parents > n - 1)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
+  if (n > 64) return fail(OBNSL_ERR_INVALID_ARGUMENT, "num_of_vars must be in [0, 64]");
+  if (max_parents + 1 > (uint32_t)KMAX)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be at most OBNSL_MAX_SUBSET - 1 = 7");
+  obnsl_status st = check_kind(kind);
+  if (st != OBNSL_OK) return st;
+  st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  // the tables grow as n * 2^n (the reference's :30-40 need n * 2^n * 16 bytes
+  // and overflow `1 << n` from n = 31): refuse what the device cannot hold
+  if (n > 31)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT,
+                "num_of_vars must be in [0, 31] for the exact subset dynamic program "
+                "(its tables grow as n * 2^n)");
+  const uint64_t combs = 1ull << n, half = combs >> 1;
+  const uint64_t need = combs * 9 + (uint64_t)n * half * 12 + (64ull << 20);
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  if (need > free_b)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT,
+                "num_of_vars too large for the exact subset dynamic program on this device "
+                "(its tables grow as n * 2^n)");
+  // scores of every subset size the search asks for, on the device
+  std::vector<DevBuf<double>> tables(max_parents + 1);
+  DpScores sc;
+  std::memset(&sc, 0, sizeof(sc));
+  sc.max_scored = max_parents + 1;
+  st = obnsl_precount(d, max_parents + 1, 0, 1);
+  if (st != OBNSL_OK) return st;
+  for (uint32_t k = 1; k <= max_parents + 1; ++k) {
+    HIP_TRY(tables[k - 1].ensure(std::max<uint64_t>(binom_host(n, k) * k, 1)));
+    st = obnsl_score_all(d, kind, ess, k, 0, 1, tables[k - 1].p, 1);
+    if (st != OBNSL_OK) return st;
+    sc.tbl[k - 1] = tables[k - 1].p;
+  }
+  DevBuf<double> best_gs, bls, total;
+  DevBuf<signed char> best_ch;
+  DevBuf<uint32_t> bps;
+  DevBuf<uint64_t> parents;
+  HIP_TRY(best_gs.ensure(combs));
+  HIP_TRY(best_ch.ensure(combs));
+  HIP_TRY(bls.ensure(std::max<uint64_t>((uint64_t)n * half, 1)));
+  HIP_TRY(bps.ensure(std::max<uint64_t>((uint64_t)n * half, 1)));
+  HIP_TRY(parents.ensure(n));
+  HIP_TRY(total.ensure(1));
+  HIP_TRY(hipMemsetAsync(best_gs.p, 0, sizeof(double), d->stream));  // best_gs[empty set] = 0 (:42-44)
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((combs + 255) / 256, 1u << 20);
+  for (uint32_t level = 1; level <= n; ++level)
+    hipLaunchKernelGGL(dp_level_kernel, dim3(grid), dim3(256), 0, d->stream, n, level, sc,
+                       d->d_binom.p, best_gs.p, best_ch.p, bls.p, bps.p);
+  hipLaunchKernelGGL(dp_backtrack_kernel, dim3(1), dim3(64), 0, d->stream, n, best_gs.p, best_ch.p,
+                     bps.p, parents.p, total.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(parents_out, parents.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, d->stream));
+  double tot = 0.0;
+  HIP_TRY(hipMemcpyAsync(&tot, total.p, sizeof(double), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  if (total_score_out) *total_score_out = tot;
   return OBNSL_OK;
 }
 

@@ -47,6 +47,8 @@ SIGNATURES = {
     "obnsl_best_parents": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _f64p,
                                           _u32p, _u64p]),
     "obnsl_best_parents_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _vp]),
+    "obnsl_exhaustive_search": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
+                                               _u64p, _f64p]),
     "obnsl_binomial": (ctypes.c_uint64, [ctypes.c_uint32, ctypes.c_uint32]),
     "obnsl_unrank": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, _u32p]),
     "obnsl_rank": (ctypes.c_uint64, [_u32p, ctypes.c_uint32]),
@@ -191,6 +193,15 @@ class Data:
         """Asynchronous; out_ptr: device pointer to 3 * n doubles (score, size, rank per node)."""
         arr = (_vp * len(score_ptrs))(*score_ptrs)
         _check(lib.obnsl_best_parents_device(self._h, arr, max_parents, out_ptr))
+
+    def exhaustive_search(self, max_parents, kind=BDEU, ess=1.0):
+        """(list of parent lists per node, total score) of the optimal DAG."""
+        masks = np.zeros(self.n, dtype=np.uint64)
+        total = ctypes.c_double(0.0)
+        _check(lib.obnsl_exhaustive_search(self._h, kind, ess, max_parents,
+                                           masks.ctypes.data_as(_u64p), ctypes.byref(total)))
+        parents = [[j for j in range(self.n) if (int(m) >> j) & 1] for m in masks]
+        return parents, total.value
 
     def kernel_time(self, k, reset=False):
         """(total ms, launches) of the size-k counting kernel since the last reset."""

@@ -179,22 +179,26 @@ PDAG exhaustive_search(const DataframeWrapper& df, const ScoreType& score_type,
   if (n == 0 || max_parents > n - 1)
     throw std::invalid_argument("max_parents must be in [0, num_of_vars-1]");
   if (n > 64) throw std::invalid_argument("num_of_vars must be in [0, 64]");
-  // the reference's n * 2^n tables (:30-40) stop being allocatable long before
-  // 64 variables (and its `1 << n` overflows from 31); refuse instead of failing
-  // in the allocator.  Per-node best parent sets for larger n come from the
-  // engine's score tables directly.
-  if (n > 30)
-    throw std::invalid_argument(
-        "num_of_vars must be in [0, 30] for the exact subset dynamic program "
-        "(its tables grow as n * 2^n)");
-  if (max_parents + 1 > OBNSL_MAX_SUBSET)
-    throw std::invalid_argument("max_parents must be at most OBNSL_MAX_SUBSET - 1 = 7");
   const obnsl_score_kind kind = score_kind(score_type);
   if (kind != OBNSL_SCORE_BDEU && kind != OBNSL_SCORE_BIC)
     throw std::invalid_argument("Unsupported score type.");
-  const auto tables = score_tables(df, score_type, max_parents);
-  py::gil_scoped_release nogil;
-  return search_from_tables(n, max_parents, tables, nullptr);
+  // Scores, subset dynamic program and back-track all run on the device
+  // (obnsl_exhaustive_search).  The reference's n * 2^n tables (:30-40) stop
+  // being allocatable long before 64 variables (and its `1 << n` overflows from
+  // 31); the engine refuses what the device cannot hold instead of failing in the
+  // allocator.  search_from_tables() below is the same program on the host.
+  EngineData& eng = df.engine();
+  std::vector<uint64_t> masks(n, 0);
+  {
+    py::gil_scoped_release nogil;
+    check(obnsl_exhaustive_search(eng.get(), kind, score_ess(score_type),
+                                  static_cast<uint32_t>(max_parents), masks.data(), nullptr));
+  }
+  PDAG g(n);
+  for (size_t v = 0; v < n; ++v)
+    for (size_t j = 0; j < n; ++j)
+      if (masks[v] >> j & 1) g.add_edge(j, v);
+  return g;
 }
 
 }  // namespace obnsl

@@ -117,3 +117,53 @@ def test_exhaustive_search_matches_oracle(ob, cards, N, mp, kind):
     assert abs(total - want_total) <= 1e-9 * abs(want_total)
     if kind == "bdeu":      # BDeu is score equivalent; BIC optima need not be unique classes
         assert graphs.markov_equivalent(have, want)
+
+
+@pytest.mark.parametrize("case", ["mixed12", "ties7", "bic9", "mp0", "n16"])
+def test_device_dp_equals_host_dp_on_the_same_scores(ob, case):
+    """obnsl_exhaustive_search (scores + subset DP + back-track on the GPU) must
+    return exactly the DAG and total that the host restatement of the reference's
+    DP (search_from_tables) returns on the engine's own score tables: same
+    arithmetic, same tie rules."""
+    from openbnsl_amd import engine, graphs, synth
+    kind, mp = engine.BDEU, 3
+    if case == "mixed12":
+        codes, card, _, _ = synth.random_bn([2, 3, 4, 2, 3, 2, 4, 3, 2, 3, 2, 4], 20_000, seed=12)
+    elif case == "ties7":       # duplicated columns: exact score ties everywhere
+        base, card0, _, _ = synth.random_bn([2, 3, 2], 2_000, seed=4)
+        codes = np.ascontiguousarray(np.concatenate([base, base, base[:1]]))
+        card = np.concatenate([card0, card0, card0[:1]])
+    elif case == "bic9":
+        codes, card, _, _ = synth.random_bn([2, 3, 4, 2, 3, 2, 4, 3, 2], 6_000, seed=5)
+        kind, mp = engine.BIC, 2
+    elif case == "mp0":
+        codes, card, _, _ = synth.random_bn([2, 3, 4, 2], 1_000, seed=6)
+        mp = 0
+    else:
+        codes, card, _, _ = synth.random_bn([2, 3, 2, 2, 3, 2, 4, 2, 3, 2, 2, 3, 2, 4, 2, 3], 5_000, seed=16)
+    n = codes.shape[0]
+    d = engine.Data(codes, card)
+    parents, total = d.exhaustive_search(mp, kind)
+    tables = [d.score_all(k, kind).ravel().tolist() for k in range(1, mp + 2)]
+    g, host_total = ob.structure_learning.search_from_tables(n, mp, tables)
+    assert parents == graphs.parent_lists(g)
+    assert total == host_total
+    assert graphs.is_acyclic(parents) and all(len(p) <= mp for p in parents)
+    d.close()
+
+
+def test_exhaustive_search_error_paths(ob):
+    from openbnsl_amd import engine, synth
+    codes, card, names = synth.asia(2_000, seed=0)
+    d = engine.Data(codes, card)
+    with pytest.raises(ValueError, match=r"max_parents must be in \[0, num_of_vars-1\]"):
+        d.exhaustive_search(8)
+    with pytest.raises(ValueError, match="Unsupported score type"):
+        d.exhaustive_search(2, engine.K2)
+    d.close()
+    wide = np.zeros((40, 64), dtype=np.uint8)
+    wide[:, ::2] = 1
+    d = engine.Data(wide, [2] * 40)
+    with pytest.raises(ValueError, match="dynamic program"):
+        d.exhaustive_search(2)
+    d.close()
