@@ -96,6 +96,36 @@ def cpu_baseline(codes, card, names, max_parents, budget_s=20.0):
     return out, omp
 
 
+def exhaustive_search_wallclock(engine, with_cpu):
+    """Second half of the metric: wall-clock of the whole exhaustive search
+    (scores + subset DP + back-track, data resident) on BASELINE config 1 and on
+    a 20-variable case; the oracle's restatement of the reference search is timed
+    beside config 1 (the reference's own search cannot be compiled here)."""
+    from openbnsl_amd import synth
+    res = []
+    cases = [("asia8_1e5_bdeu_mp2", synth.asia(100_000, 0)[:2], 2),
+             ("random20_1e4_bdeu_mp3", synth.random_bn(([2, 3, 2, 4, 2, 3] * 4)[:20], 10_000, seed=20)[:2], 3)]
+    for name, (codes, card), mp in cases:
+        d = engine.Data(codes, card)
+        d.exhaustive_search(mp)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            parents, total = d.exhaustive_search(mp)
+            ts.append(time.perf_counter() - t0)
+        d.close()
+        rec = {"workload": name, "ms": float(np.median(ts)) * 1e3, "total_score": total,
+               "edges": int(sum(len(p) for p in parents))}
+        if with_cpu and codes.shape[0] <= 8:
+            import oracle
+            t0 = time.perf_counter()
+            _, ototal = oracle.exhaustive_search(codes, card, mp)
+            rec["cpu_port_ms"] = (time.perf_counter() - t0) * 1e3
+            rec["cpu_total_score"] = ototal
+        res.append(rec)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +240,8 @@ def main():
                      "kernel_ms": kernel_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch},
     }
+    if rank == 0 and world == 1:
+        out["exhaustive_search"] = exhaustive_search_wallclock(engine, not args.no_cpu_baseline)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             base, omp = cpu_baseline(codes, card, names, mp)
