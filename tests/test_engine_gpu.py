@@ -278,3 +278,27 @@ def test_hot_path_device_result_matches_host_result(engine):
     ms, launches = hot.data.kernel_time(4)
     assert launches == 3 and ms > 0
     hot.close()
+
+
+def test_largest_subset_sizes_and_tiny_problems(engine):
+    """Subset sizes 7 and 8 (4+3 and 4+4 variable splits of the bit-GEMM) and
+    degenerate data sets (one and two variables)."""
+    import oracle
+    from openbnsl_amd import synth
+    codes, card, _, _ = synth.random_bn([2, 2, 3, 2, 2, 3, 2, 2, 2], 3_000, seed=8, min_prob=0.05)
+    d = engine.Data(codes, card)
+    for k in (7, 8):
+        want = oracle.score_all(codes, card, k, nthreads=4)
+        assert rel_err(d.score_all(k), want) <= REL, k
+    with pytest.raises(ValueError):
+        d.score_all(9 if engine.MAX_SUBSET < 9 else 10)
+    d.close()
+    for cards, N in (([3], 100), ([2, 4], 257)):
+        codes, card, _, _ = synth.random_bn(cards, N, seed=1, n_arcs=len(cards) - 1)
+        d = engine.Data(codes, card)
+        for k in range(1, len(cards) + 1):
+            assert rel_err(d.score_all(k), oracle.score_all(codes, card, k)) <= REL
+        parents, total = d.exhaustive_search(len(cards) - 1)
+        want, wtotal = oracle.exhaustive_search(codes, card, len(cards) - 1)
+        assert abs(total - wtotal) <= 1e-9 * abs(wtotal)
+        d.close()
