@@ -466,8 +466,10 @@ struct ReducedViews {
 // evaluates ONE sum per table, stores it in G[rank], and lane i < k writes
 // score i = G(S) - Gprev[rank(S without v_i)]; Gprev belongs to the next smaller
 // subset size (g0 for the empty set).  scores may be null (G only).
+// (templated on the subset size so that the per-variable loops unroll exactly)
+template <int KT>
 __global__ __launch_bounds__(64) void score_reduced_kernel(
-    ReducedViews views, const RowGroupDesc* __restrict__ rgs, uint32_t nrgs, uint32_t k,
+    ReducedViews views, const RowGroupDesc* __restrict__ rgs, uint32_t nrgs,
     uint64_t ntables, uint32_t tables_per_wg, const uint32_t* __restrict__ card,
     const uint64_t* __restrict__ binom, uint32_t num_rows, int kind, double ess,
     double* __restrict__ G, const double* __restrict__ Gprev, double g0,
@@ -475,7 +477,8 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
   extern __shared__ __attribute__((aligned(16))) uint32_t E[];
   __shared__ SizeView sv[KMAX + 1];
   __shared__ uint32_t s_vars[KMAX], s_cards[KMAX];
-  __shared__ uint64_t pat_base[1 << KMAX];  // first counter of the reduced table of a support pattern
+  __shared__ uint64_t pat_base[1 << KT];  // first counter of the reduced table of a support pattern
+  constexpr uint32_t k = KT;
   const uint32_t lane = threadIdx.x;
 #pragma unroll
   for (int j = 0; j <= KMAX; ++j)
@@ -1364,11 +1367,22 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
     uint32_t tpw = (uint32_t)std::min<uint64_t>(2, std::max<uint64_t>(1, b->ntables / 4096));
     if (tpw_env) tpw = tpw_env;
     const uint32_t grid = (uint32_t)((b->ntables + tpw - 1) / tpw);
-    hipLaunchKernelGGL(score_reduced_kernel, dim3(grid), dim3(64),
-                       (size_t)max_cells * sizeof(uint32_t), d->stream, views, b->rgs.p, b->nrgs, k,
-                       b->ntables, tpw, d->d_card.p, d->d_binom.p, (uint32_t)d->N,
-                       (int)kind, ess,
-                       plan->G.p, gprev, g0, scores);
+#define OBNSL_LAUNCH_SCORER(KT)                                                                  \
+  hipLaunchKernelGGL((score_reduced_kernel<KT>), dim3(grid), dim3(64),                           \
+                     (size_t)max_cells * sizeof(uint32_t), d->stream, views, b->rgs.p, b->nrgs,  \
+                     b->ntables, tpw, d->d_card.p, d->d_binom.p, (uint32_t)d->N, (int)kind, ess, \
+                     plan->G.p, gprev, g0, scores)
+    switch (k) {
+      case 1: OBNSL_LAUNCH_SCORER(1); break;
+      case 2: OBNSL_LAUNCH_SCORER(2); break;
+      case 3: OBNSL_LAUNCH_SCORER(3); break;
+      case 4: OBNSL_LAUNCH_SCORER(4); break;
+      case 5: OBNSL_LAUNCH_SCORER(5); break;
+      case 6: OBNSL_LAUNCH_SCORER(6); break;
+      case 7: OBNSL_LAUNCH_SCORER(7); break;
+      default: OBNSL_LAUNCH_SCORER(8); break;
+    }
+#undef OBNSL_LAUNCH_SCORER
     HIP_TRY(hipGetLastError());
   }
   plan->g_epoch = d->epoch;
