@@ -1471,6 +1471,35 @@ obnsl_status run_hist_range(obnsl_data* d, uint32_t k, uint64_t lo, uint64_t hi,
   return OBNSL_OK;
 }
 
+// Which counting path serves subset size k.  Reduced mode (count only states
+// 1..r-1 with the bit-GEMM, expand in the scorer) whenever the largest full table
+// of this size fits the scorer's LDS AND the cost model prefers it: the
+// bit-plane form costs ~ (reduced cells) x (32-row words), the per-row histogram
+// ~ (tables) x (rows); measured on MI355X 6.7e-5 ns per cell-word (at ~80 % tile
+// fill) against 4.5e-4 ns per table-row, i.e. the histogram wins above ~215
+// reduced cells per table.
+obnsl_status choose_reduced(obnsl_data* d, uint32_t k, bool* use_reduced, uint64_t* max_cells_out) {
+  std::vector<uint32_t> sorted_card(d->card);
+  std::sort(sorted_card.rbegin(), sorted_card.rend());
+  uint64_t max_cells = 1;
+  for (uint32_t i = 0; i < k; ++i) max_cells *= sorted_card[i];
+  if (max_cells_out) *max_cells_out = max_cells;
+  static const bool allow_reduced = std::getenv("OBNSL_NO_REDUCED") == nullptr;
+  static const bool force_hist = std::getenv("OBNSL_FORCE_HIST") != nullptr;
+  static const bool force_bits = std::getenv("OBNSL_FORCE_BITGEMM") != nullptr;
+  bool use = allow_reduced && max_cells <= REDUCED_MAX_CELLS && !force_hist;
+  if (use && !force_bits) {
+    Plan* full = nullptr;
+    obnsl_status st = build_plan(d, k, 0, 1, true, &full);
+    if (st != OBNSL_OK) return st;
+    const double est_bit = (double)full->batches[0]->ncells * (double)d->wp * 6.7e-5;
+    const double est_hist = (double)binom_host(d->n, k) * (double)d->N * 4.5e-4;
+    if (est_hist < est_bit) use = false;
+  }
+  *use_reduced = use;
+  return OBNSL_OK;
+}
+
 obnsl_status check_kind(obnsl_score_kind kind) {
   if (kind == OBNSL_SCORE_BDEU || kind == OBNSL_SCORE_BIC) return OBNSL_OK;
   return fail(OBNSL_ERR_UNSUPPORTED, "Unsupported score type.");
@@ -1713,28 +1742,10 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
     d_scores = tmp.p;
   }
 
-  // Reduced mode (count only states 1..r-1, expand in the scorer) whenever the
-  // largest full table of this size fits the scorer's LDS; otherwise every state
-  // is counted directly.
-  std::vector<uint32_t> sorted_card(d->card);
-  std::sort(sorted_card.rbegin(), sorted_card.rend());
   uint64_t max_cells = 1;
-  for (uint32_t i = 0; i < k; ++i) max_cells *= sorted_card[i];
-  static const bool allow_reduced = std::getenv("OBNSL_NO_REDUCED") == nullptr;
-  static const bool force_hist = std::getenv("OBNSL_FORCE_HIST") != nullptr;
-  bool use_reduced = allow_reduced && max_cells <= REDUCED_MAX_CELLS && !force_hist;
-  if (use_reduced && std::getenv("OBNSL_FORCE_BITGEMM") == nullptr) {
-    // The bit-plane form costs ~ (reduced cells) x (32-row words); the per-row
-    // histogram costs ~ (tables) x (rows).  Measured on MI355X: 6.7e-5 ns per
-    // cell-word (at ~80 % tile fill) against 4.5e-4 ns per table-row, i.e. the
-    // histogram wins above ~215 reduced cells per table.
-    Plan* full = nullptr;
-    st = build_plan(d, k, 0, 1, true, &full);
-    if (st != OBNSL_OK) return st;
-    const double est_bit = (double)full->batches[0]->ncells * (double)d->wp * 6.7e-5;
-    const double est_hist = (double)nsub * (double)d->N * 4.5e-4;
-    if (est_hist < est_bit) use_reduced = false;
-  }
+  bool use_reduced = false;
+  st = choose_reduced(d, k, &use_reduced, &max_cells);
+  if (st != OBNSL_OK) return st;
   if (use_reduced) {
     ReducedViews views;
     std::memset(&views, 0, sizeof(views));
@@ -1822,11 +1833,22 @@ obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "shard must be in [0, num_shards)");
   obnsl_status st = set_device(d->device);
   if (st != OBNSL_OK) return st;
-  std::vector<uint32_t> sorted_card(d->card);
-  std::sort(sorted_card.rbegin(), sorted_card.rend());
-  uint64_t max_cells = 1;
-  for (uint32_t i = 0; i < kmax; ++i) max_cells *= sorted_card[i];
-  if (std::getenv("OBNSL_NO_REDUCED") || max_cells > REDUCED_MAX_CELLS) return OBNSL_OK;  // nothing to share
+  // sizes whose scorer reads reduced count tables (a size served by the
+  // histogram path needs none, and neither do the sizes above it)
+  uint32_t top_size = 0;
+  const bool whole_request = true;
+  for (uint32_t j = 1; j <= kmax; ++j) {
+    bool red = false;
+    st = choose_reduced(d, j, &red, nullptr);
+    if (st != OBNSL_OK) return st;
+    if (!red) break;
+    top_size = j;
+  }
+  if (top_size == 0) return OBNSL_OK;  // nothing to share
+  // if the requested top size itself goes through the histogram path, the sizes
+  // below it are all counted whole (none of them is "the sharded top size")
+  const bool top_is_requested = whole_request && top_size == kmax;
+  kmax = top_size;
   if (!d->side) {
     HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&d->side_fork, hipEventDisableTiming));
@@ -1846,7 +1868,7 @@ obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32
   Plan* top = nullptr;
   st = build_plan(d, kmax, 0, 1, true, &top);
   if (st != OBNSL_OK) return st;
-  if (num_shards > 1 && top->total_items > 64) {
+  if (top_is_requested && num_shards > 1 && top->total_items > 64) {
     st = build_plan(d, kmax, shard, num_shards, true, &top);
     if (st != OBNSL_OK) return st;
   }
