@@ -130,6 +130,41 @@ __device__ __forceinline__ uint4 and4(uint4 a, uint4 b) {
   return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w);
 }
 
+// acc += popc(x) as ONE instruction.  Written out because the optimiser otherwise
+// may regroup a chain of such sums into popc(x) + 0 pairs joined by a three-way
+// add: 25 % more vector instructions in a loop that is bound by their issue rate.
+__device__ __forceinline__ void popc_acc(uint32_t& acc, uint32_t x) {
+  asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
+}
+
+// One 32-word slab of the tile product: acc[i][j] += popc(A row (tm + 16 i) & B
+// column (tn + 16 j)) for i < TT and j < JM.  JM < TT skips the column groups of
+// a tile on the edge of the staircase that hold no valid column.
+template <int TT, int JM>
+__device__ __forceinline__ void tile_mac(const uint32_t* __restrict__ sA,
+                                         const uint32_t* __restrict__ sB, uint32_t tm,
+                                         uint32_t tn, uint32_t (&acc)[TT][TT]) {
+#pragma unroll 1
+  for (int kq = 0; kq < KCW / 4; ++kq) {
+    uint4 a[TT], b[JM];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+      a[i] = *reinterpret_cast<const uint4*>(&sA[(tm + 16 * i) * LDS_STRIDE + kq * 4]);
+#pragma unroll
+    for (int j = 0; j < JM; ++j)
+      b[j] = *reinterpret_cast<const uint4*>(&sB[(tn + 16 * j) * LDS_STRIDE + kq * 4]);
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+      for (int j = 0; j < JM; ++j) {
+        popc_acc(acc[i][j], a[i].x & b[j].x);
+        popc_acc(acc[i][j], a[i].y & b[j].y);
+        popc_acc(acc[i][j], a[i].z & b[j].z);
+        popc_acc(acc[i][j], a[i].w & b[j].w);
+      }
+  }
+}
+
 // C[row][col] += sum over this split's words of popc(A[row][w] & B[col][w]).
 // 256 threads; a workgroup owns a (16 TT) x (16 TT) tile of C (TT = 8: 128 x 128,
 // TT = 4: 64 x 64); thread (tm, tn) owns rows tm + 16 i and columns tn + 16 j
@@ -169,6 +204,9 @@ __global__ __launch_bounds__(256) void bitgemm_kernel(
   const uint32_t st_off = rl * LDS_STRIDE + q * 4;  // this thread's uint4 in a slab (row rl)
 
   const uint32_t tn = tid & 15, tm = tid >> 4;
+  // rows are ordered by their number of valid columns: the tile's last row has the most
+  const uint32_t lim = rows[min(row0 + TB, nrows) - 1].ncols;
+  const uint32_t jm = (use_atomics & 2) ? (uint32_t)TT : lim > col0 ? min((lim - col0 + 15) / 16, (uint32_t)TT) : 1;
   uint32_t acc[TT][TT];
 #pragma unroll
   for (int i = 0; i < TT; ++i)
@@ -217,24 +255,21 @@ __global__ __launch_bounds__(256) void bitgemm_kernel(
     if (more) issue_loads(step + 1);
     const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
     const uint32_t* sB = sA + TB * LDS_STRIDE;
-#pragma unroll 1
-    for (int kq = 0; kq < KCW / 4; ++kq) {
-      uint4 a[TT], b[TT];
-#pragma unroll
-      for (int i = 0; i < TT; ++i)
-        a[i] = *reinterpret_cast<const uint4*>(&sA[(tm + 16 * i) * LDS_STRIDE + kq * 4]);
-#pragma unroll
-      for (int j = 0; j < TT; ++j)
-        b[j] = *reinterpret_cast<const uint4*>(&sB[(tn + 16 * j) * LDS_STRIDE + kq * 4]);
-#pragma unroll
-      for (int i = 0; i < TT; ++i)
-#pragma unroll
-        for (int j = 0; j < TT; ++j) {
-          acc[i][j] += __popc(a[i].x & b[j].x);
-          acc[i][j] += __popc(a[i].y & b[j].y);
-          acc[i][j] += __popc(a[i].z & b[j].z);
-          acc[i][j] += __popc(a[i].w & b[j].w);
-        }
+    // only the first jm column groups hold valid columns (uniform over the workgroup)
+    if constexpr (TT == 4) {
+      switch (jm) {
+        case 1: tile_mac<TT, 1>(sA, sB, tm, tn, acc); break;
+        case 2: tile_mac<TT, 2>(sA, sB, tm, tn, acc); break;
+        case 3: tile_mac<TT, 3>(sA, sB, tm, tn, acc); break;
+        default: tile_mac<TT, 4>(sA, sB, tm, tn, acc); break;
+      }
+    } else {
+      switch ((jm + 1) >> 1) {
+        case 1: tile_mac<TT, 2>(sA, sB, tm, tn, acc); break;
+        case 2: tile_mac<TT, 4>(sA, sB, tm, tn, acc); break;
+        case 3: tile_mac<TT, 6>(sA, sB, tm, tn, acc); break;
+        default: tile_mac<TT, TT>(sA, sB, tm, tn, acc); break;
+      }
     }
     if (more) write_slab(buf ^ 1);
     __syncthreads();
@@ -250,7 +285,7 @@ __global__ __launch_bounds__(256) void bitgemm_kernel(
       const uint32_t c = col0 + tn + 16 * j;
       if (c >= rd.ncols) continue;
       uint32_t* dst = counts + rd.out_base + (uint64_t)c * rd.M;
-      if (use_atomics) {
+      if (use_atomics & 1) {
         if (acc[i][j]) atomicAdd(dst, acc[i][j]);
       } else {
         *dst = acc[i][j];
@@ -1308,8 +1343,9 @@ obnsl_status launch_count(obnsl_data* d, const Plan* plan, const Batch* b, uint3
   if (b->nitems < want) ksplit = std::min<uint32_t>((want + b->nitems - 1) / b->nitems, max_split);
   const uint32_t sps = (steps_total + ksplit - 1) / ksplit;
   ksplit = (steps_total + sps - 1) / sps;
-  const int atomics = ksplit > 1;
-  if (atomics) HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
+  static const int nojskip = std::getenv("OBNSL_NO_JSKIP") ? 2 : 0;
+  const int atomics = (ksplit > 1 ? 1 : 0) | nojskip;
+  if (atomics & 1) HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
   if (d->ev_used >= 4096) {  // bound the pool: fold what has been recorded so far
     obnsl_status st = resolve_events(d);
     if (st != OBNSL_OK) return st;
@@ -1858,7 +1894,9 @@ obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32
   HIP_TRY(hipEventRecord(d->side_fork, d->stream));
   HIP_TRY(hipStreamWaitEvent(d->side, d->side_fork, 0));
   d->count_on_side = true;
-  for (uint32_t j = 1; j < kmax && st == OBNSL_OK; ++j) {
+  // largest first: the side stream's kernels run one after another, each sharing
+  // the chip with the top size's launch on the main stream
+  for (uint32_t j = kmax - 1; j >= 1 && st == OBNSL_OK; --j) {
     Plan* full = nullptr;
     st = build_plan(d, j, 0, 1, true, &full);
     if (st == OBNSL_OK) st = ensure_counts(d, full);

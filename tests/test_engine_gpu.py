@@ -264,7 +264,8 @@ def test_hot_path_device_result_matches_host_result(engine):
     synchronous obnsl_best_parents and a brute-force arg-max over oracle scores."""
     import oracle
     from openbnsl_amd import synth
-    from openbnsl_amd.pipeline import HotPath, best_parents_reference
+    from openbnsl_amd.pipeline import HotPath
+    from helpers import best_parents_reference
     codes, card, _, _ = synth.random_bn([2, 3, 4, 2, 3, 4, 3, 2, 4, 3], 12_000, seed=31)
     hot = HotPath(codes, card, 3)
     for _ in range(3):

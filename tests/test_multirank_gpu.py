@@ -15,7 +15,8 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     import oracle
     from openbnsl_amd import synth
-    from openbnsl_amd.pipeline import HotPath, best_parents_reference
+    from openbnsl_amd.pipeline import HotPath
+    from helpers import best_parents_reference
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
