@@ -508,7 +508,7 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
     uint64_t ntables, uint32_t tables_per_wg, const uint32_t* __restrict__ card,
     const uint64_t* __restrict__ binom, uint32_t num_rows, int kind, double ess,
     double* __restrict__ G, const double* __restrict__ Gprev, double g0,
-    double* __restrict__ scores) {
+    double* __restrict__ scores, const double* __restrict__ lg_alpha) {
   extern __shared__ __attribute__((aligned(16))) uint32_t E[];
   __shared__ SizeView sv[KMAX + 1];
   __shared__ uint32_t s_vars[KMAX], s_cards[KMAX];
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
     double gsum = 0.0;
     if (kind == OBNSL_SCORE_BDEU) {
       const double a = ess / (double)cells;
-      const double lg_a = lgamma_pos(a);
+      const double lg_a = lg_alpha[cells];  // lgamma(a): the same for every table of this size
       for (uint32_t c = lane; c < cells; c += 64) {
         const uint32_t nc = E[c];
         if (nc) gsum += lgamma_pos((double)nc + a) - lg_a;
@@ -1046,6 +1046,9 @@ struct obnsl_data {
   hipStream_t side = nullptr;                         // second stream for obnsl_precount (default priority)
   hipEvent_t side_fork = nullptr, side_join = nullptr;
   bool count_on_side = false;                         // launch_count targets `side` instead of `stream`
+  const void* side_pending = nullptr;                 // plan whose counts are still being produced on `side`
+  // per ess: lgamma(ess / c) for c = 1..REDUCED_MAX_CELLS (index c), from the host's libm
+  std::map<double, std::unique_ptr<DevBuf<double>>> lg_alpha;
   hipStream_t count_stream() const { return count_on_side ? side : stream; }
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // around each bit-GEMM launch
   std::vector<uint32_t> ev_size;                      // subset size of each pending pair
@@ -1377,9 +1380,21 @@ obnsl_status launch_count(obnsl_data* d, const Plan* plan, const Batch* b, uint3
   return OBNSL_OK;
 }
 
+// Makes the main stream wait for the side stream's outstanding count launch.
+obnsl_status join_side(obnsl_data* d) {
+  if (d->side_pending) {
+    HIP_TRY(hipStreamWaitEvent(d->stream, d->side_join, 0));
+    d->side_pending = nullptr;
+  }
+  return OBNSL_OK;
+}
+
 // Reduced mode: make plan->red hold the counts of the current planes.
 obnsl_status ensure_counts(obnsl_data* d, Plan* plan) {
-  if (plan->counted_epoch == d->epoch) return OBNSL_OK;
+  if (plan->counted_epoch == d->epoch) {
+    if (d->side_pending == plan) return join_side(d);
+    return OBNSL_OK;
+  }
   obnsl_status st = launch_count(d, plan, plan->batches[0].get(), plan->red.p);
   if (st != OBNSL_OK) return st;
   plan->counted_epoch = d->epoch;
@@ -1392,6 +1407,17 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
                             uint64_t max_cells, obnsl_score_kind kind, double ess,
                             const double* gprev, double g0, double* scores) {
   HIP_TRY(plan->G.ensure(std::max<uint64_t>(binom_host(d->n, k), 1)));
+  const double* lg_alpha = nullptr;
+  if (kind == OBNSL_SCORE_BDEU) {
+    auto& slot = d->lg_alpha[ess];
+    if (!slot) {
+      std::vector<double> h(REDUCED_MAX_CELLS + 1, 0.0);
+      for (uint64_t c = 1; c <= REDUCED_MAX_CELLS; ++c) h[c] = std::lgamma(ess / (double)c);
+      slot = std::make_unique<DevBuf<double>>();
+      HIP_TRY(slot->upload(h));
+    }
+    lg_alpha = slot->p;
+  }
   const Batch* b = plan->batches[0].get();
   if (b->ntables) {
     // a few consecutive tables per wavefront amortise the row-group search and
@@ -1407,7 +1433,7 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
   hipLaunchKernelGGL((score_reduced_kernel<KT>), dim3(grid), dim3(64),                           \
                      (size_t)max_cells * sizeof(uint32_t), d->stream, views, b->rgs.p, b->nrgs,  \
                      b->ntables, tpw, d->d_card.p, d->d_binom.p, (uint32_t)d->N, (int)kind, ess, \
-                     plan->G.p, gprev, g0, scores)
+                     plan->G.p, gprev, g0, scores, lg_alpha)
     switch (k) {
       case 1: OBNSL_LAUNCH_SCORER(1); break;
       case 2: OBNSL_LAUNCH_SCORER(2); break;
@@ -1547,6 +1573,8 @@ obnsl_status set_device(int device) {
 }
 
 obnsl_status run_pack(obnsl_data* d) {
+  obnsl_status js = join_side(d);  // a count launch may still be reading the planes
+  if (js != OBNSL_OK) return js;
   dim3 grid((d->wp + 255) / 256, d->n + 1);
   hipLaunchKernelGGL(pack_planes_kernel, grid, dim3(256), 0, d->stream, d->codes.p, d->N,
                      d->stride, d->n, d->d_card.p, d->d_plane_base.p, d->planes.p, d->wp,
@@ -1890,18 +1918,12 @@ obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32
     HIP_TRY(hipEventCreateWithFlags(&d->side_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d->side_join, hipEventDisableTiming));
   }
-  // fork: the side stream starts after everything queued so far (the pack)
-  HIP_TRY(hipEventRecord(d->side_fork, d->stream));
-  HIP_TRY(hipStreamWaitEvent(d->side, d->side_fork, 0));
-  d->count_on_side = true;
-  // largest first: the side stream's kernels run one after another, each sharing
-  // the chip with the top size's launch on the main stream
-  for (uint32_t j = kmax - 1; j >= 1 && st == OBNSL_OK; --j) {
-    Plan* full = nullptr;
-    st = build_plan(d, j, 0, 1, true, &full);
-    if (st == OBNSL_OK) st = ensure_counts(d, full);
-  }
-  d->count_on_side = false;
+  // The top size is counted on the side stream, the sizes below it (largest
+  // first) on the main stream, so that their scorers -- queued on the main stream
+  // by the obnsl_score_all calls that follow -- run while the top size is still
+  // being counted.  The main stream joins the side stream where the top size's
+  // counts are first used (ensure_counts) or before the planes change (run_pack).
+  st = join_side(d);
   if (st != OBNSL_OK) return st;
   Plan* top = nullptr;
   st = build_plan(d, kmax, 0, 1, true, &top);
@@ -1910,12 +1932,23 @@ obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32
     st = build_plan(d, kmax, shard, num_shards, true, &top);
     if (st != OBNSL_OK) return st;
   }
-  st = ensure_counts(d, top);
-  if (st != OBNSL_OK) return st;
-  // join: later work on the main stream sees the side stream's counts
-  HIP_TRY(hipEventRecord(d->side_join, d->side));
-  HIP_TRY(hipStreamWaitEvent(d->stream, d->side_join, 0));
-  return OBNSL_OK;
+  if (top->counted_epoch != d->epoch) {
+    // fork: the side stream starts after everything queued so far (the pack)
+    HIP_TRY(hipEventRecord(d->side_fork, d->stream));
+    HIP_TRY(hipStreamWaitEvent(d->side, d->side_fork, 0));
+    d->count_on_side = true;
+    st = ensure_counts(d, top);
+    d->count_on_side = false;
+    if (st != OBNSL_OK) return st;
+    HIP_TRY(hipEventRecord(d->side_join, d->side));
+    d->side_pending = top;
+  }
+  for (uint32_t j = kmax - 1; j >= 1 && st == OBNSL_OK; --j) {
+    Plan* full = nullptr;
+    st = build_plan(d, j, 0, 1, true, &full);
+    if (st == OBNSL_OK) st = ensure_counts(d, full);
+  }
+  return st;
 }
 
 obnsl_status obnsl_score_subsets(obnsl_data* d, obnsl_score_kind kind, double ess,

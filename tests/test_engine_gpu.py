@@ -117,7 +117,9 @@ def test_score_subsets_matches_score_all(engine):
         subs = oracle.enumerate_subsets(7, k)
         full = d.score_all(k)
         pick = subs[::3]
-        assert np.array_equal(d.score_subsets(pick), full[::3])
+        # the list form sums each score's two terms directly, the batch form takes
+        # differences of per-table sums: same terms, different grouping
+        assert rel_err(d.score_subsets(pick), full[::3]) <= 1e-12
     d.close()
 
 
