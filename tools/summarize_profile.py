@@ -1,0 +1,57 @@
+"""Copies the summaries of one tools/profile_bench.sh run from gpurun_out/ into
+profiles/ and derives profiles/pmc_summary.json (HBM traffic per launch of the
+dominant kernel).
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch; on gfx950 FETCH_SIZE
+counts 64 B per 128-B request of 16-B-per-lane coalesced loads, so it is doubled;
+WRITE_SIZE is exact for one-dword-per-lane atomics and 16-B stores."""
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag, name = sys.argv[1], sys.argv[2]          # e.g. prof r1g
+dominant = sys.argv[3] if len(sys.argv) > 3 else "bitgemm_kernel<2, 2, 4>"
+workload = sys.argv[4] if len(sys.argv) > 4 else "alarm37_1e6_bdeu_mp3"
+
+
+def one(pattern):
+    return glob.glob(pattern)[0]
+
+
+shutil.copy(one(f"gpurun_out/{tag}_trace/*/*kernel_stats.csv"), f"profiles/{name}_bench_kernel_stats.csv")
+shutil.copy(f"gpurun_out/{tag}_bench_under_trace.json", f"profiles/{name}_bench_under_trace.json")
+
+
+def per_launch(path, counter):
+    per = {}
+    for r in csv.DictReader(open(path)):
+        if dominant in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    vals = list(per.values())
+    return sum(vals) / len(vals), len(vals)
+
+
+fetch_csv = one(f"gpurun_out/{tag}_fetch/*/*counter_collection.csv")
+write_csv = one(f"gpurun_out/{tag}_write/*/*counter_collection.csv")
+shutil.copy(fetch_csv, f"profiles/{name}_pmc_fetch_size.csv")
+shutil.copy(write_csv, f"profiles/{name}_pmc_write_size.csv")
+f_kib, nf = per_launch(fetch_csv, "FETCH_SIZE")
+w_kib, nw = per_launch(write_csv, "WRITE_SIZE")
+summary = {
+    "workload": workload,
+    "kernel": dominant,
+    "launches_sampled": [nf, nw],
+    "fetch_bytes_per_launch_corrected": f_kib * 1024 * 2,
+    "write_bytes_per_launch": w_kib * 1024,
+    "traffic_bytes_per_launch": f_kib * 1024 * 2 + w_kib * 1024,
+    "note": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/{name}_pmc_*_size.csv); "
+            "counters are in KiB; FETCH_SIZE doubled (gfx950 reports half the bytes of 16-B-per-lane coalesced loads)",
+}
+for path in ("profiles/pmc_summary.json", f"profiles/{name}_pmc_summary.json"):
+    with open(path, "w") as f:
+        json.dump(summary, f, indent=1)
+print(json.dumps(summary, indent=1))
+for r in csv.DictReader(open(f"profiles/{name}_bench_kernel_stats.csv")):
+    print(r["Name"][:60], r["Calls"], r["AverageNs"], r["Percentage"])
