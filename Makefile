@@ -20,9 +20,10 @@ else
 all: $(ENGINE) oracle
 endif
 
-$(ENGINE): openbnsl_amd/csrc/engine.hip include/obnsl_engine.h
+ENGINE_SRC := openbnsl_amd/csrc/engine.hip openbnsl_amd/csrc/anneal.cpp
+$(ENGINE): $(ENGINE_SRC) openbnsl_amd/csrc/engine_internal.h include/obnsl_engine.h
 	mkdir -p openbnsl_amd/lib
-	$(HIPCC) $(HIPFLAGS) -shared $< -o $@
+	$(HIPCC) $(HIPFLAGS) -Iopenbnsl_amd/csrc -pthread -shared $(ENGINE_SRC) -o $@
 
 $(PYMOD): $(HOST_SRC) $(HOST_HDR) $(ENGINE)
 	g++ -O2 -std=c++17 -fPIC -shared -fvisibility=hidden -Wall -Iinclude -Iopenbnsl_amd/host \

@@ -72,6 +72,10 @@ obnsl_status obnsl_data_create(const uint8_t* codes, uint64_t num_rows, uint64_t
                                int codes_on_device, obnsl_data** out);
 obnsl_status obnsl_data_destroy(obnsl_data* d);
 
+/* Replaces the fields num_of_datapoints / num_of_vars of DataframeWrapper
+ * (include/base/dataframe_wrapper.h:35-36).  Either output may be null. */
+obnsl_status obnsl_data_shape(const obnsl_data* d, uint64_t* num_rows, uint32_t* num_vars);
+
 /* Work is queued on this HIP stream (a hipStream_t; NULL = the null stream).
  * Calls that return results to host memory synchronise it before returning. */
 obnsl_status obnsl_data_set_stream(obnsl_data* d, void* hip_stream);
@@ -158,6 +162,38 @@ obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_sco
 obnsl_status obnsl_exhaustive_search(obnsl_data* d, obnsl_score_kind kind, double ess,
                                      uint32_t max_parents, uint64_t* parents_out,
                                      double* total_score_out);
+
+/* Replaces simulated_annealing(df, score_type, max_parents, max_iters,
+ * init_temp, cooling_rate, is_deterministic, seed, num_chains)
+ * (src/structure_learning/simulated_annealing.cpp:100-159; defaults of its
+ * binding: bindings/submodules/structure_learning.cpp:19-30).  The reference
+ * builds one contingency table over all rows per step (:77-81); here the local
+ * scores come from the GPU (every parent set of at most max_parents parents in
+ * one pass, or one table per step when that is cheaper) and the chains run on
+ * host threads with the reference's generator, seeds (seed + c * 1234567) and
+ * draw order.  num_chains == 0: one chain per host thread (OMP_NUM_THREADS if
+ * set).  Outputs (host): num_parents_out[v] and the ascending parent ids
+ * parents_out[v * max(max_parents,1) + j] of the best graph of the best chain;
+ * best_score_out (may be null) = its total score.
+ * max_parents >= num_vars -> OBNSL_ERR_INVALID_ARGUMENT "max_parents out of range"
+ * (:109-111).  max_parents == 0 returns the empty graph (the reference's chain
+ * does not honour the bound in that one case). */
+obnsl_status obnsl_simulated_annealing(obnsl_data* d, obnsl_score_kind kind, double ess,
+                                       uint32_t max_parents, uint64_t max_iters,
+                                       double init_temp, double cooling_rate,
+                                       int is_deterministic, uint64_t seed, uint32_t num_chains,
+                                       uint32_t* parents_out, uint32_t* num_parents_out,
+                                       double* best_score_out);
+
+/* The same chains on score tables the caller already holds (host memory, no
+ * GPU): tables[k-1][rank * k + i] = score(v_i | S \ {v_i}) for the size-k subset
+ * S of colex rank `rank`, k = 1..max_parents+1 -- the layout obnsl_score_all
+ * writes. */
+obnsl_status obnsl_anneal_tables(uint32_t num_vars, uint32_t max_parents,
+                                 const double* const* tables, uint64_t max_iters,
+                                 double init_temp, double cooling_rate, int is_deterministic,
+                                 uint64_t seed, uint32_t num_chains, uint32_t* parents_out,
+                                 uint32_t* num_parents_out, double* best_score_out);
 
 /* colex rank <-> subset helpers (host, no GPU). */
 uint64_t obnsl_binomial(uint32_t n, uint32_t k);

@@ -1,0 +1,387 @@
+// anneal.cpp -- simulated annealing over DAGs, driven by the engine's scores.
+//
+// Replaces simulated_annealing() of the reference
+// (src/structure_learning/simulated_annealing.cpp:16-159).  There every step
+// walks all N rows to build one contingency table and evaluates one local score
+// from it (:77-81).  Here the scores of every (child, parent set) with at most
+// max_parents parents come from the GPU in one pass (obnsl_score_all) and a
+// step is a table lookup; when that table would cost more than the steps need
+// (very many variables, few steps) each step asks the GPU for the one table it
+// needs (obnsl_score_subsets) and remembers the answer.
+//
+// The chains themselves are short sequential host programs.  They draw from
+// the same generator, through the same standard-library distributions and in
+// the same order as the reference's chain, so a chain started from the same
+// seed proposes the same moves; it takes the same decisions as long as no
+// acceptance test is decided by the last bits of a score.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <random>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "engine_internal.h"
+
+using obnsl_internal::fail;
+
+namespace {
+
+// score(child | parents), asked for as the sorted variable list `vars`
+// (parents and child together) and the child's position in it.
+class ScoreSource {
+ public:
+  virtual ~ScoreSource() = default;
+  virtual bool get(const uint32_t* vars, uint32_t k, uint32_t child_pos, double* out) = 0;
+};
+
+// Complete tables on the host: tables[k-1][rank * k + i], rank = colex rank.
+class TableSource final : public ScoreSource {
+ public:
+  TableSource(const double* const* tables) : tables_(tables) {}
+  bool get(const uint32_t* vars, uint32_t k, uint32_t child_pos, double* out) override {
+    *out = tables_[k - 1][obnsl_rank(vars, k) * k + child_pos];
+    return true;
+  }
+
+ private:
+  const double* const* tables_;
+};
+
+// One GPU table per miss, memoised; shared by the chains under a lock (the
+// engine serves one call at a time per data set).
+class LazySource final : public ScoreSource {
+ public:
+  LazySource(obnsl_data* d, obnsl_score_kind kind, double ess) : d_(d), kind_(kind), ess_(ess) {}
+  bool get(const uint32_t* vars, uint32_t k, uint32_t child_pos, double* out) override {
+    const uint64_t key = obnsl_rank(vars, k);
+    std::lock_guard<std::mutex> lock(mu_);
+    auto& memo = memo_[k];
+    auto it = memo.find(key);
+    if (it == memo.end()) {
+      double sc[OBNSL_MAX_SUBSET];
+      status = obnsl_score_subsets(d_, kind_, ess_, vars, k, 1, sc);
+      if (status != OBNSL_OK) {
+        message = obnsl_last_error();
+        return false;
+      }
+      it = memo.emplace(key, std::vector<double>(sc, sc + k)).first;
+    }
+    *out = it->second[child_pos];
+    return true;
+  }
+  obnsl_status status = OBNSL_OK;
+  std::string message;
+
+ private:
+  obnsl_data* d_;
+  obnsl_score_kind kind_;
+  double ess_;
+  std::mutex mu_;
+  std::unordered_map<uint64_t, std::vector<double>> memo_[OBNSL_MAX_SUBSET + 1];
+};
+
+struct Settings {
+  uint32_t n = 0, max_parents = 0;
+  uint64_t max_iters = 0;
+  double init_temp = 1.0, cooling_rate = 1.0;
+  bool sorted_sets = false;  // is_deterministic
+};
+
+struct ChainOutcome {
+  double best_score = -1e100;  // reference: simulated_annealing.cpp:117
+  std::vector<std::vector<uint32_t>> best_parents;
+  bool ok = true;
+};
+
+// The order in which the reference's parent container hands back its members:
+// ascending for std::set (is_deterministic), the hash table's own order for
+// std::unordered_set<size_t> built from `seq` (include/graph/pdag_with_adjlist.h:5-8,
+// simulated_annealing.cpp:85-86).  A removal picks "the i-th parent" in that
+// order (:73-74), so it is part of the chain's behaviour.
+std::vector<uint32_t> container_order(const std::vector<uint32_t>& seq, bool sorted_sets) {
+  std::vector<uint32_t> out(seq);
+  if (sorted_sets) {
+    std::sort(out.begin(), out.end());
+    return out;
+  }
+  std::vector<size_t> wide(seq.begin(), seq.end());
+  const std::unordered_set<size_t> built(wide.begin(), wide.end());
+  const std::unordered_set<size_t> stored = built;
+  out.assign(stored.begin(), stored.end());
+  return out;
+}
+
+class Chain {
+ public:
+  Chain(const Settings& cfg, ScoreSource& src)
+      : cfg_(cfg), src_(src), pa_(cfg.n), is_parent_(size_t(cfg.n) * cfg.n, 0), mark_(cfg.n, 0) {}
+
+  void run(uint64_t seed, ChainOutcome& res) {
+    const uint32_t n = cfg_.n;
+    std::vector<double> ls(n);
+    for (uint32_t v = 0; v < n; ++v)
+      if (!src_.get(&v, 1, 0, &ls[v])) {
+        res.ok = false;
+        return;
+      }
+    double current = std::accumulate(ls.begin(), ls.end(), 0.0);
+    res.best_score = current;
+    res.best_parents = pa_;
+
+    std::mt19937_64 gen(seed);
+    std::uniform_real_distribution<double> unit(0.0, 1.0);
+    std::uniform_int_distribution<size_t> any_node(0, n - 1);
+    std::vector<uint32_t> proposal, vars, order(n - 1);
+
+    double temp = cfg_.init_temp;
+    for (uint64_t it = 0; it < cfg_.max_iters; ++it, temp *= cfg_.cooling_rate) {
+      const uint32_t child = static_cast<uint32_t>(any_node(gen));
+      const std::vector<uint32_t>& cur = pa_[child];
+      bool grow;
+      if (cur.empty())
+        grow = true;
+      else if (cur.size() == cfg_.max_parents)
+        grow = false;
+      else
+        grow = unit(gen) < 0.5;
+
+      proposal = cur;
+      if (grow) {
+        // a random order of all other nodes; the first one that is not yet a
+        // parent and is not a descendant of the child joins (:57-70)
+        for (uint32_t v = 0, j = 0; v < n; ++v)
+          if (v != child) order[j++] = v;
+        std::shuffle(order.begin(), order.end(), gen);
+        bool found = false;
+        for (uint32_t p : order) {
+          if (is_parent_[size_t(child) * n + p]) continue;
+          if (is_ancestor(child, p)) continue;
+          proposal.push_back(p);
+          std::sort(proposal.begin(), proposal.end());
+          found = true;
+          break;
+        }
+        if (!found) continue;
+      } else {
+        std::uniform_int_distribution<size_t> which(0, proposal.size() - 1);
+        proposal.erase(proposal.begin() + static_cast<std::ptrdiff_t>(which(gen)));
+      }
+
+      vars = proposal;
+      vars.push_back(child);
+      std::sort(vars.begin(), vars.end());
+      const uint32_t pos =
+          static_cast<uint32_t>(std::find(vars.begin(), vars.end(), child) - vars.begin());
+      double candidate;
+      if (!src_.get(vars.data(), static_cast<uint32_t>(vars.size()), pos, &candidate)) {
+        res.ok = false;
+        return;
+      }
+      const double delta = candidate - ls[child];
+      if (delta >= 0.0 || std::exp(delta / temp) > unit(gen)) {
+        for (uint32_t p : pa_[child]) is_parent_[size_t(child) * n + p] = 0;
+        pa_[child] = container_order(proposal, cfg_.sorted_sets);
+        for (uint32_t p : pa_[child]) is_parent_[size_t(child) * n + p] = 1;
+        ls[child] = candidate;
+        current += delta;
+        if (current > res.best_score) {
+          res.best_score = current;
+          res.best_parents = pa_;
+        }
+      }
+    }
+    for (auto& p : res.best_parents) std::sort(p.begin(), p.end());
+  }
+
+ private:
+  // Is `a` an ancestor of `x` (or x itself)?  Adding x -> a would then close a
+  // cycle.  Same answer as has_path(x, a) of the reference's adjacency list
+  // (include/graph/pdag_with_adjlist.h:43-59), which climbs parent links from x.
+  bool is_ancestor(uint32_t a, uint32_t x) {
+    ++stamp_;
+    stack_.clear();
+    stack_.push_back(x);
+    mark_[x] = stamp_;
+    while (!stack_.empty()) {
+      const uint32_t v = stack_.back();
+      stack_.pop_back();
+      if (v == a) return true;
+      for (uint32_t u : pa_[v])
+        if (mark_[u] != stamp_) {
+          mark_[u] = stamp_;
+          stack_.push_back(u);
+        }
+    }
+    return false;
+  }
+
+  const Settings& cfg_;
+  ScoreSource& src_;
+  std::vector<std::vector<uint32_t>> pa_;  // parents of each node, in container order
+  std::vector<uint8_t> is_parent_;         // [child][parent]
+  std::vector<uint64_t> mark_;
+  uint64_t stamp_ = 0;
+  std::vector<uint32_t> stack_;
+};
+
+uint32_t default_chains() {
+  // reference: omp_get_max_threads() when num_chains is 0 (:113-115)
+  if (const char* e = std::getenv("OMP_NUM_THREADS")) {
+    const long v = std::strtol(e, nullptr, 10);
+    if (v > 0) return static_cast<uint32_t>(v);
+  }
+  const unsigned hc = std::thread::hardware_concurrency();
+  return hc ? hc : 1;
+}
+
+obnsl_status anneal(const Settings& cfg, ScoreSource& src, uint64_t seed, uint32_t num_chains,
+                    uint32_t* parents_out, uint32_t* num_parents_out, double* best_score_out) {
+  if (num_chains == 0) num_chains = default_chains();
+  std::vector<ChainOutcome> outcome(num_chains);
+  const uint32_t workers = std::min<uint32_t>(num_chains, default_chains());
+  std::vector<std::thread> pool;
+  for (uint32_t w = 0; w < workers; ++w)
+    pool.emplace_back([&, w] {
+      for (uint32_t c = w; c < num_chains; c += workers) {
+        Chain chain(cfg, src);
+        chain.run(seed + c * 1234567ULL, outcome[c]);  // per-chain seeds: :131
+      }
+    });
+  for (auto& t : pool) t.join();
+  uint32_t best = 0;
+  for (uint32_t c = 0; c < num_chains; ++c) {
+    if (!outcome[c].ok) return OBNSL_ERR_RUNTIME;
+    if (outcome[c].best_score > outcome[best].best_score) best = c;  // first maximum wins (:135-136)
+  }
+  const uint32_t width = std::max<uint32_t>(cfg.max_parents, 1);
+  for (uint32_t v = 0; v < cfg.n; ++v) {
+    const auto& p = outcome[best].best_parents[v];
+    num_parents_out[v] = static_cast<uint32_t>(p.size());
+    for (size_t j = 0; j < p.size(); ++j) parents_out[size_t(v) * width + j] = p[j];
+  }
+  if (best_score_out) *best_score_out = outcome[best].best_score;
+  return OBNSL_OK;
+}
+
+obnsl_status check_common(uint32_t n, uint32_t max_parents, uint64_t max_iters, double init_temp,
+                          const void* parents_out, const void* num_parents_out) {
+  if (!parents_out || !num_parents_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (n == 0 || max_parents >= n)  // reference: :109-111
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents out of range");
+  if (max_parents + 1 > OBNSL_MAX_SUBSET)
+    return fail(OBNSL_ERR_UNSUPPORTED, "max_parents + 1 exceeds OBNSL_MAX_SUBSET");
+  (void)max_iters;
+  (void)init_temp;
+  return OBNSL_OK;
+}
+
+// The reference's chain ignores max_parents == 0: an empty parent set always
+// grows (:47-48) and no size ever equals the bound again.  The only graph that
+// honours the argument is the empty one, which is what is returned here.
+void empty_graph(uint32_t n, uint32_t* num_parents_out) {
+  std::memset(num_parents_out, 0, sizeof(uint32_t) * n);
+}
+
+}  // namespace
+
+extern "C" {
+
+obnsl_status obnsl_anneal_tables(uint32_t num_vars, uint32_t max_parents,
+                                 const double* const* tables, uint64_t max_iters,
+                                 double init_temp, double cooling_rate, int is_deterministic,
+                                 uint64_t seed, uint32_t num_chains, uint32_t* parents_out,
+                                 uint32_t* num_parents_out, double* best_score_out) {
+  obnsl_status st = check_common(num_vars, max_parents, max_iters, init_temp, parents_out, num_parents_out);
+  if (st != OBNSL_OK) return st;
+  if (!tables) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  for (uint32_t k = 1; k <= max_parents + 1; ++k)
+    if (!tables[k - 1]) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null score table");
+  Settings cfg;
+  cfg.n = num_vars;
+  cfg.max_parents = max_parents;
+  cfg.max_iters = max_iters;
+  cfg.init_temp = init_temp;
+  cfg.cooling_rate = cooling_rate;
+  cfg.sorted_sets = is_deterministic != 0;
+  TableSource src(tables);
+  if (max_parents == 0) {
+    empty_graph(num_vars, num_parents_out);
+    if (best_score_out) {
+      double total = 0.0;
+      for (uint32_t v = 0; v < num_vars; ++v) total += tables[0][v];
+      *best_score_out = total;
+    }
+    return OBNSL_OK;
+  }
+  return anneal(cfg, src, seed, num_chains, parents_out, num_parents_out, best_score_out);
+}
+
+obnsl_status obnsl_simulated_annealing(obnsl_data* d, obnsl_score_kind kind, double ess,
+                                       uint32_t max_parents, uint64_t max_iters,
+                                       double init_temp, double cooling_rate,
+                                       int is_deterministic, uint64_t seed, uint32_t num_chains,
+                                       uint32_t* parents_out, uint32_t* num_parents_out,
+                                       double* best_score_out) {
+  if (!d) return fail(OBNSL_ERR_INVALID_ARGUMENT, "data is null");
+  uint64_t rows = 0;
+  uint32_t n = 0;
+  obnsl_status st = obnsl_data_shape(d, &rows, &n);
+  if (st != OBNSL_OK) return st;
+  st = check_common(n, max_parents, max_iters, init_temp, parents_out, num_parents_out);
+  if (st != OBNSL_OK) return st;
+  if (kind != OBNSL_SCORE_BDEU && kind != OBNSL_SCORE_BIC)
+    return fail(OBNSL_ERR_UNSUPPORTED, "Unsupported score type.");
+  if (num_chains == 0) num_chains = default_chains();
+
+  // Complete tables or one table per step?  Cost of the complete pass: every
+  // score reads one column of `rows` bytes (algorithmic), at a conservative
+  // 3e13 B/s of the counting kernels; cost of a step on demand: one small
+  // launch chain and a synchronisation, about 1e-4 s.  The complete tables must
+  // also fit 2^28 doubles on the host.
+  const uint32_t top = max_parents == 0 ? 1 : max_parents + 1;
+  long double total_scores = 0;
+  for (uint32_t k = 1; k <= top; ++k) total_scores += (long double)obnsl_binomial(n, k) * k;
+  const long double table_s = total_scores * (long double)rows / 3e13L;
+  const long double steps_s = (long double)max_iters * num_chains * 1e-4L;
+  bool complete = total_scores <= (long double)(1ull << 28) && table_s <= steps_s + 0.05L;
+  // OBNSL_ANNEAL_SCORES=tables|steps overrides the choice (tests exercise both)
+  if (const char* e = std::getenv("OBNSL_ANNEAL_SCORES")) {
+    if (!std::strcmp(e, "steps")) complete = false;
+    if (!std::strcmp(e, "tables") && total_scores <= (long double)(1ull << 28)) complete = true;
+  }
+
+  Settings cfg;
+  cfg.n = n;
+  cfg.max_parents = max_parents;
+  cfg.max_iters = max_iters;
+  cfg.init_temp = init_temp;
+  cfg.cooling_rate = cooling_rate;
+  cfg.sorted_sets = is_deterministic != 0;
+
+  if (complete || max_parents == 0) {
+    std::vector<std::vector<double>> tables(top);
+    std::vector<const double*> ptrs(top);
+    for (uint32_t k = 1; k <= top; ++k) {
+      tables[k - 1].resize((size_t)obnsl_binomial(n, k) * k);
+      st = obnsl_score_all(d, kind, ess, k, 0, 1, tables[k - 1].data(), 0);
+      if (st != OBNSL_OK) return st;
+      ptrs[k - 1] = tables[k - 1].data();
+    }
+    return obnsl_anneal_tables(n, max_parents, ptrs.data(), max_iters, init_temp, cooling_rate,
+                               is_deterministic, seed, num_chains, parents_out, num_parents_out,
+                               best_score_out);
+  }
+  LazySource src(d, kind, ess);
+  st = anneal(cfg, src, seed, num_chains, parents_out, num_parents_out, best_score_out);
+  if (st != OBNSL_OK) return fail(src.status != OBNSL_OK ? src.status : st,
+                                  src.message.empty() ? "simulated annealing failed" : src.message);
+  return OBNSL_OK;
+}
+
+}  // extern "C"

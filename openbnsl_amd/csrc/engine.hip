@@ -37,6 +37,7 @@
 #include <tuple>
 #include <vector>
 
+#include "engine_internal.h"
 #include "obnsl_engine.h"
 
 namespace {
@@ -54,6 +55,12 @@ obnsl_status fail(obnsl_status st, const std::string& msg) {
   g_err = msg;
   return st;
 }
+
+}  // namespace
+
+obnsl_status obnsl_internal::fail(obnsl_status st, const std::string& msg) { return ::fail(st, msg); }
+
+namespace {
 
 #define HIP_TRY(expr)                                                                  \
   do {                                                                                 \
@@ -1696,6 +1703,13 @@ obnsl_status obnsl_data_pack(obnsl_data* d) {
   obnsl_status st = set_device(d->device);
   if (st != OBNSL_OK) return st;
   return run_pack(d);
+}
+
+obnsl_status obnsl_data_shape(const obnsl_data* d, uint64_t* num_rows, uint32_t* num_vars) {
+  if (!d) return fail(OBNSL_ERR_INVALID_ARGUMENT, "data is null");
+  if (num_rows) *num_rows = d->N;
+  if (num_vars) *num_vars = d->n;
+  return OBNSL_OK;
 }
 
 obnsl_status obnsl_num_subsets(const obnsl_data* d, uint32_t k, uint64_t* num) {

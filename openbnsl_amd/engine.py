@@ -33,6 +33,7 @@ SIGNATURES = {
                                          _u32p, ctypes.c_int, ctypes.c_int,
                                          ctypes.POINTER(_vp)]),
     "obnsl_data_destroy": (ctypes.c_int, [_vp]),
+    "obnsl_data_shape": (ctypes.c_int, [_vp, _u64p, _u32p]),
     "obnsl_data_set_stream": (ctypes.c_int, [_vp, _vp]),
     "obnsl_data_pack": (ctypes.c_int, [_vp]),
     "obnsl_count": (ctypes.c_int, [_vp, _u32p, ctypes.c_uint32, _u64p, ctypes.c_uint64]),
@@ -49,6 +50,14 @@ SIGNATURES = {
     "obnsl_best_parents_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _vp]),
     "obnsl_exhaustive_search": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
                                                _u64p, _f64p]),
+    "obnsl_simulated_annealing": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
+                                                 ctypes.c_uint64, ctypes.c_double, ctypes.c_double,
+                                                 ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32,
+                                                 _u32p, _u32p, _f64p]),
+    "obnsl_anneal_tables": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp),
+                                           ctypes.c_uint64, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32,
+                                           _u32p, _u32p, _f64p]),
     "obnsl_binomial": (ctypes.c_uint64, [ctypes.c_uint32, ctypes.c_uint32]),
     "obnsl_unrank": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, _u32p]),
     "obnsl_rank": (ctypes.c_uint64, [_u32p, ctypes.c_uint32]),
@@ -104,6 +113,23 @@ def local_score(counts, cards, child_idx, kind=BDEU, ess=1.0, device=0):
     _check(lib.obnsl_local_score(device, c.ctypes.data_as(_u64p), cd.ctypes.data_as(_u32p),
                                  len(cd), child_idx, kind, ess, ctypes.byref(out)))
     return out.value
+
+
+def anneal_tables(n, max_parents, tables, max_iters=10000, init_temp=1.0, cooling_rate=0.9995,
+                  is_deterministic=False, seed=0, num_chains=0):
+    """Simulated annealing on host score tables (no GPU): tables[k-1] is the
+    float64 [C(n,k), k] table of subset size k.  Returns (parent lists, score)."""
+    keep = [np.ascontiguousarray(t, dtype=np.float64) for t in tables]
+    arr = (_vp * len(keep))(*[t.ctypes.data for t in keep])
+    width = max(max_parents, 1)
+    par = np.zeros((n, width), dtype=np.uint32)
+    cnt = np.zeros(n, dtype=np.uint32)
+    total = ctypes.c_double(0.0)
+    _check(lib.obnsl_anneal_tables(n, max_parents, arr, max_iters, init_temp, cooling_rate,
+                                   int(is_deterministic), seed, num_chains,
+                                   par.ctypes.data_as(_u32p), cnt.ctypes.data_as(_u32p),
+                                   ctypes.byref(total)))
+    return [par[v, :cnt[v]].tolist() for v in range(n)], total.value
 
 
 class Data:
@@ -202,6 +228,19 @@ class Data:
                                            masks.ctypes.data_as(_u64p), ctypes.byref(total)))
         parents = [[j for j in range(self.n) if (int(m) >> j) & 1] for m in masks]
         return parents, total.value
+
+    def simulated_annealing(self, max_parents, max_iters=10000, init_temp=1.0, cooling_rate=0.9995,
+                            is_deterministic=False, seed=0, num_chains=0, kind=BDEU, ess=1.0):
+        """(list of parent lists per node, total score) of the best graph found."""
+        width = max(max_parents, 1)
+        par = np.zeros((self.n, width), dtype=np.uint32)
+        cnt = np.zeros(self.n, dtype=np.uint32)
+        total = ctypes.c_double(0.0)
+        _check(lib.obnsl_simulated_annealing(self._h, kind, ess, max_parents, max_iters, init_temp,
+                                             cooling_rate, int(is_deterministic), seed, num_chains,
+                                             par.ctypes.data_as(_u32p), cnt.ctypes.data_as(_u32p),
+                                             ctypes.byref(total)))
+        return [par[v, :cnt[v]].tolist() for v in range(self.n)], total.value
 
     def kernel_time(self, k, reset=False):
         """(total ms, launches) of the size-k counting kernel since the last reset."""

@@ -120,6 +120,12 @@ struct PDAG {
 PDAG exhaustive_search(const DataframeWrapper& df, const ScoreType& score_type,
                        size_t max_parents, bool is_deterministic);
 
+// reference: include/structure_learning/simulated_annealing.h:20-28
+PDAG simulated_annealing(const DataframeWrapper& df, const ScoreType& score_type,
+                         size_t max_parents, size_t max_iters, double init_temp,
+                         double cooling_rate, bool is_deterministic, uint64_t seed,
+                         size_t num_chains);
+
 // The score tables the search consumes: tables[k-1][rank*k + i], k = 1..max_parents+1.
 std::vector<std::vector<double>> score_tables(const DataframeWrapper& df,
                                               const ScoreType& score_type, size_t max_parents);

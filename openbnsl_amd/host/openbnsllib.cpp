@@ -56,6 +56,7 @@ PYBIND11_MODULE(openbnsllib, m) {
       .def(py::init<size_t>())
       .def(py::init<const PDAG&>())
       .def_readonly("num_vars", &PDAG::num_vars)
+      .def_readonly("parents", &PDAG::parents)
       .def("has_edge", &PDAG::has_edge, py::arg("from"), py::arg("to"))
       .def("add_edge", &PDAG::add_edge, py::arg("from"), py::arg("to"))
       .def("remove_edge", &PDAG::remove_edge, py::arg("from"), py::arg("to"));
@@ -75,6 +76,12 @@ PYBIND11_MODULE(openbnsllib, m) {
   sl.def("exhaustive_search", &exhaustive_search, "Run exhaustive search algorithm",
          py::arg("df"), py::arg("score_type"), py::arg("max_parents"),
          py::arg("is_deterministic") = false);
+  // reference: bindings/submodules/structure_learning.cpp:19-30 (same defaults)
+  sl.def("simulated_annealing", &simulated_annealing, "Run simulated annealing algorithm",
+         py::arg("df"), py::arg("score_type"), py::arg("max_parents"),
+         py::arg("max_iters") = 10000, py::arg("init_temp") = 1.0,
+         py::arg("cooling_rate") = 0.9995, py::arg("is_deterministic") = false,
+         py::arg("seed") = 0, py::arg("num_chains") = 0);
   // Not in the reference: the score tables the search consumes, and the search
   // on given tables (host only; lets the dynamic program be tested without a GPU).
   sl.def("score_tables", &score_tables, py::arg("df"), py::arg("score_type"),

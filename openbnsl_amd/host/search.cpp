@@ -201,4 +201,32 @@ PDAG exhaustive_search(const DataframeWrapper& df, const ScoreType& score_type,
   return g;
 }
 
+// reference: src/structure_learning/simulated_annealing.cpp:100-159.  The
+// chains and their score lookups run inside the engine (obnsl_simulated_annealing).
+PDAG simulated_annealing(const DataframeWrapper& df, const ScoreType& score_type,
+                         size_t max_parents, size_t max_iters, double init_temp,
+                         double cooling_rate, bool is_deterministic, uint64_t seed,
+                         size_t num_chains) {
+  const size_t n = df.num_of_vars;
+  if (max_parents >= n) throw std::invalid_argument("max_parents out of range");  // :109-111
+  const obnsl_score_kind kind = score_kind(score_type);
+  if (kind != OBNSL_SCORE_BDEU && kind != OBNSL_SCORE_BIC)
+    throw std::invalid_argument("Unsupported score type.");
+  EngineData& eng = df.engine();
+  const size_t width = max_parents ? max_parents : 1;
+  std::vector<uint32_t> parents(n * width, 0), count(n, 0);
+  {
+    py::gil_scoped_release nogil;
+    check(obnsl_simulated_annealing(eng.get(), kind, score_ess(score_type),
+                                    static_cast<uint32_t>(max_parents), max_iters, init_temp,
+                                    cooling_rate, is_deterministic ? 1 : 0, seed,
+                                    static_cast<uint32_t>(num_chains), parents.data(),
+                                    count.data(), nullptr));
+  }
+  PDAG g(n);
+  for (size_t v = 0; v < n; ++v)
+    for (size_t j = 0; j < count[v]; ++j) g.add_edge(parents[v * width + j], v);
+  return g;
+}
+
 }  // namespace obnsl

@@ -7,6 +7,8 @@
 // generate tests/golden, and as the "reference" CPU baseline of bench.py.
 // src/structure_learning/exhaustive_search.cpp is NOT part of this build: it
 // includes <boost/multiprecision/cpp_int.hpp>, which this image lacks.
+// src/structure_learning/simulated_annealing.cpp (a caller of the same table +
+// score pair) needs nothing the image lacks and is linked in as it is.
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -15,6 +17,7 @@
 #include "base/contingency_table.h"    // reference: include/base/contingency_table.h
 #include "base/dataframe_wrapper.h"    // reference: include/base/dataframe_wrapper.h
 #include "score/local_score.h"         // reference: include/score/local_score.h
+#include "structure_learning/simulated_annealing.h"  // reference: include/structure_learning/simulated_annealing.h
 #include "utils/combmask2vec.h"        // reference: include/utils/combmask2vec.h
 
 namespace py = pybind11;
@@ -75,4 +78,24 @@ PYBIND11_MODULE(openbnsl_ref, m) {
           return py::make_tuple(std::chrono::duration<double>(t1 - t0).count(), scores);
         },
         py::arg("df"), py::arg("subsets"), py::arg("ess") = 1.0);
+
+  // The reference's simulated_annealing (src/structure_learning/simulated_annealing.cpp:100-159)
+  // with the defaults of its binding (bindings/submodules/structure_learning.cpp:19-30);
+  // returns (seconds, parents per node) so that the same call serves as a CPU timing.
+  m.def("simulated_annealing",
+        [](const DataframeWrapper& df, double ess, size_t max_parents, size_t max_iters,
+           double init_temp, double cooling_rate, bool is_deterministic, uint64_t seed,
+           size_t num_chains) {
+          const auto t0 = std::chrono::steady_clock::now();
+          PDAG g = simulated_annealing(df, BDeu{ess}, max_parents, max_iters, init_temp,
+                                       cooling_rate, is_deterministic, seed, num_chains);
+          const auto t1 = std::chrono::steady_clock::now();
+          std::vector<std::vector<size_t>> parents(g.num_vars);
+          for (size_t v = 0; v < g.num_vars; ++v)
+            parents[v].assign(g.parents[v].begin(), g.parents[v].end());
+          return py::make_tuple(std::chrono::duration<double>(t1 - t0).count(), parents);
+        },
+        py::arg("df"), py::arg("ess"), py::arg("max_parents"), py::arg("max_iters") = 10000,
+        py::arg("init_temp") = 1.0, py::arg("cooling_rate") = 0.9995,
+        py::arg("is_deterministic") = false, py::arg("seed") = 0, py::arg("num_chains") = 0);
 }

@@ -123,6 +123,34 @@ def main():
                                     ["lung", "smoke"], ["tub", "asia"]],
     }
 
+    # simulated_annealing of the reference (src/structure_learning/simulated_annealing.cpp),
+    # a caller of the same table + score pair: parents per node of the returned graph
+    sa_frames = {
+        "asia20k": ("openbnsl_amd.synth.asia(20000, seed=0)", synth.asia(20000, seed=0)[:2]),
+        "mixed12_3k": ("openbnsl_amd.synth.random_bn([2,3,4,2,3,4,3,2,4,3,2,2], 3000, seed=11, n_arcs=16)",
+                       synth.random_bn([2, 3, 4, 2, 3, 4, 3, 2, 4, 3, 2, 2], 3000, seed=11, n_arcs=16)[:2]),
+    }
+    sa_cases = []
+    for fname, mp, iters, t0, cool, seed, chains in [
+            ("asia20k", 3, 1000, 1.0, 0.9995, 0, 1), ("asia20k", 2, 2000, 1.0, 0.9995, 5, 3),
+            ("asia20k", 1, 500, 2.0, 0.99, 7, 2), ("mixed12_3k", 3, 3000, 1.0, 0.9995, 1, 4),
+            ("mixed12_3k", 4, 3000, 1.0, 0.9995, 2, 2), ("mixed12_3k", 2, 10000, 1.0, 0.9995, 0, 1)]:
+        codes, card = sa_frames[fname][1]
+        nms = [f"c{v:02d}" for v in range(codes.shape[0])]
+        sdf = synth.to_dataframe(codes, nms, labels=[[f"s{j}" for j in range(int(c))] for c in card])
+        sdfw = ref.DataframeWrapper(sdf)
+        for det in (True, False):
+            _, parents = ref.simulated_annealing(sdfw, 1.0, mp, iters, t0, cool, det, seed, chains)
+            sa_cases.append({"frame": fname, "ess": 1.0, "max_parents": mp, "max_iters": iters,
+                             "init_temp": t0, "cooling_rate": cool, "is_deterministic": det,
+                             "seed": seed, "num_chains": chains,
+                             "parents": [list(map(int, p)) for p in parents]})
+    meta["simulated_annealing"] = {
+        "frames": {k: {"generator": g, "sha256_codes": hashlib.sha256(c[0].tobytes()).hexdigest()}
+                   for k, (g, c) in sa_frames.items()},
+        "cases": sa_cases,
+    }
+
     # error behaviour of the reference
     errs = {}
     try:
@@ -139,6 +167,10 @@ def main():
             ref.calculate_local_score(0, [1], ct, st)
         except Exception as e:  # noqa: BLE001
             errs["unsupported_" + nm] = [type(e).__name__, str(e)]
+    try:
+        ref.simulated_annealing(dfw, 1.0, 8, 10, 1.0, 0.9995, True, 0, 1)
+    except Exception as e:  # noqa: BLE001
+        errs["sa_max_parents_out_of_range"] = [type(e).__name__, str(e)]
     meta["errors"] = errs
 
     np.savez_compressed(os.path.join(HERE, "frames.npz"), **arrays)
