@@ -111,6 +111,7 @@ def exhaustive_search_wallclock(engine, with_cpu):
         ts = []
         for _ in range(5):
             t0 = time.perf_counter()
+            d.pack()    # new row bitmaps: no count table of the previous call is reused
             parents, total = d.exhaustive_search(mp)
             ts.append(time.perf_counter() - t0)
         d.close()
@@ -123,6 +124,46 @@ def exhaustive_search_wallclock(engine, with_cpu):
             rec["cpu_port_ms"] = (time.perf_counter() - t0) * 1e3
             rec["cpu_total_score"] = ototal
         res.append(rec)
+    return res
+
+
+def simulated_annealing_wallclock(engine, data, with_cpu):
+    """Wall-clock of simulated_annealing (a caller of the same table + score pair)
+    on the resident benchmark data set and on BASELINE config 1 data, where the
+    reference's own implementation (oracle/_ref) is timed beside it on a bounded
+    number of steps."""
+    from openbnsl_amd import synth
+    res = []
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        data.pack()     # new row bitmaps: no count table of the previous call is reused
+        parents, total = data.simulated_annealing(3, 10000, seed=0, num_chains=4, is_deterministic=True)
+        ts.append(time.perf_counter() - t0)
+    res.append({"workload": "resident data set, max_parents 3, 10000 steps x 4 chains",
+                "ms": float(np.median(ts)) * 1e3, "total_score": total,
+                "edges": int(sum(len(p) for p in parents))})
+    codes, card, names = synth.asia(100_000, 0)
+    d = engine.Data(codes, card)
+    d.simulated_annealing(3, 1000, seed=0, num_chains=1, is_deterministic=True)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        d.pack()
+        parents, total = d.simulated_annealing(3, 1000, seed=0, num_chains=1, is_deterministic=True)
+        ts.append(time.perf_counter() - t0)
+    d.close()
+    rec = {"workload": "asia8_1e5_bdeu_mp3, 1000 steps x 1 chain", "ms": float(np.median(ts)) * 1e3,
+           "total_score": total, "edges": int(sum(len(p) for p in parents))}
+    if with_cpu:
+        import oracle
+        ref = oracle.ref()
+        if ref is not None:
+            dfw = ref.DataframeWrapper(synth.to_dataframe(codes, names))
+            secs, want = ref.simulated_annealing(dfw, 1.0, 3, 1000, 1.0, 0.9995, True, 0, 1)
+            rec["cpu_reference_ms"] = secs * 1e3
+            rec["same_graph_as_reference"] = [list(map(int, p)) for p in want] == parents
+    res.append(rec)
     return res
 
 
@@ -242,6 +283,7 @@ def main():
     }
     if rank == 0 and world == 1:
         out["exhaustive_search"] = exhaustive_search_wallclock(engine, not args.no_cpu_baseline)
+        out["simulated_annealing"] = simulated_annealing_wallclock(engine, data, not args.no_cpu_baseline)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             base, omp = cpu_baseline(codes, card, names, mp)

@@ -104,7 +104,8 @@ struct TableDesc {      // explicit table for the list-form / single-table score
 __global__ __launch_bounds__(256) void pack_planes_kernel(
     const uint8_t* __restrict__ codes, uint64_t N, uint64_t stride, uint32_t n,
     const uint32_t* __restrict__ card, const uint32_t* __restrict__ plane_base,
-    uint32_t* __restrict__ planes, uint32_t wp, uint32_t ones_plane) {
+    uint32_t* __restrict__ planes, uint32_t wp, uint32_t ones_plane,
+    uint32_t* __restrict__ bad_code) {
   const uint32_t w = blockIdx.x * 256 + threadIdx.x;
   if (w >= wp) return;
   const uint32_t v = blockIdx.y;
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(
   const uint4 lo = src[0], hi = src[1];
   const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   const uint32_t r = card[v], base = plane_base[v];
+  uint32_t covered = 0;  // rows whose code is one of the r states
   for (uint32_t s = 0; s < r; ++s) {
     uint32_t word = 0;
 #pragma unroll
@@ -129,7 +131,10 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(
         word |= (uint32_t)(((x[i] >> (8 * b)) & 0xffu) == s) << (4 * i + b);
     }
     planes[(size_t)(base + s) * wp + w] = word & valid;
+    covered |= word;
   }
+  // a code >= the declared cardinality: flagged (when asked) with a plain store
+  if (bad_code && (covered & valid) != valid) *bad_code = v + 1;
 }
 
 // ------------------------------------------------------------------ bit-GEMM
@@ -1579,13 +1584,13 @@ obnsl_status set_device(int device) {
   return OBNSL_OK;
 }
 
-obnsl_status run_pack(obnsl_data* d) {
+obnsl_status run_pack(obnsl_data* d, uint32_t* bad_code = nullptr) {
   obnsl_status js = join_side(d);  // a count launch may still be reading the planes
   if (js != OBNSL_OK) return js;
   dim3 grid((d->wp + 255) / 256, d->n + 1);
   hipLaunchKernelGGL(pack_planes_kernel, grid, dim3(256), 0, d->stream, d->codes.p, d->N,
                      d->stride, d->n, d->d_card.p, d->d_plane_base.p, d->planes.p, d->wp,
-                     d->ones_plane);
+                     d->ones_plane, bad_code);
   HIP_TRY(hipGetLastError());
   d->epoch++;  // every cached count table is stale now
   return OBNSL_OK;
@@ -1677,9 +1682,19 @@ obnsl_status obnsl_data_create(const uint8_t* codes, uint64_t num_rows, uint64_t
   for (uint32_t v = 0; v <= num_vars; ++v)
     for (uint32_t j = 0; j <= (uint32_t)KMAX; ++j) binom[(size_t)v * (KMAX + 1) + j] = binom_host(v, j);
   HIP_TRY(d->d_binom.upload(binom));
-  obnsl_status st = run_pack(d.get());
+  // the first pack also checks every code against its variable's cardinality:
+  // a larger code would index past the tables of the per-row counting kernels
+  DevBuf<uint32_t> bad;
+  HIP_TRY(bad.ensure(1));
+  HIP_TRY(hipMemset(bad.p, 0, sizeof(uint32_t)));
+  obnsl_status st = run_pack(d.get(), bad.p);
   if (st != OBNSL_OK) return st;
   HIP_TRY(hipStreamSynchronize(d->stream));
+  uint32_t bad_var = 0;
+  HIP_TRY(hipMemcpy(&bad_var, bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (bad_var)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "variable " + std::to_string(bad_var - 1) +
+                                                " has a code that is not below its cardinality");
   *out = d.release();
   return OBNSL_OK;
 }

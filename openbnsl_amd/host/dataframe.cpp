@@ -10,8 +10,10 @@
 // (the reference reinterprets any buffer as PyObject*, :30); a column with more
 // than 256 distinct values is an error instead of a silent uint8 wrap.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <unordered_map>
 
 #include "openbnsl_host.h"
@@ -109,11 +111,11 @@ DataframeWrapper::DataframeWrapper(const py::object& dataframe) {
 
   codes.assign(num_of_vars * num_of_datapoints, 0);
   val_idx2str.resize(num_of_vars);
-  std::vector<uint32_t> ids(num_of_datapoints);
-  for (size_t v = 0; v < num_of_vars; ++v) {
+  std::vector<uint32_t> ids(kind == 'O' ? num_of_datapoints : 0);
+  for (size_t v = 0; v < num_of_vars && kind == 'O'; ++v) {
     std::vector<std::string> labels;
     const char* col = base + static_cast<ssize_t>(v) * s1;
-    if (kind == 'O') {
+    {
       std::unordered_map<std::string, uint32_t> seen;
       PyObject* last_obj = nullptr;
       uint32_t last_id = 0;
@@ -139,25 +141,70 @@ DataframeWrapper::DataframeWrapper(const py::object& dataframe) {
         ids[i] = last_id = it->second;
         last_obj = o;
       }
-    } else {
-      std::unordered_map<int64_t, uint32_t> seen;
-      for (size_t i = 0; i < num_of_datapoints; ++i) {
-        const int64_t x = read_int(col + static_cast<ssize_t>(i) * s0, kind, isz);
-        auto it = seen.find(x);
-        if (it == seen.end()) {
-          if (labels.size() == 256)
-            throw std::invalid_argument("more than 256 distinct values in column " + col_idx2str[v]);
-          it = seen.emplace(x, labels.size()).first;
-          labels.push_back(kind == 'b' ? (x ? "True" : "False") : std::to_string(x));
-        }
-        ids[i] = it->second;
-      }
     }
     rank_codes(ids, labels, codes.data() + v * num_of_datapoints, val_idx2str[v]);
   }
+  if (kind != 'O') ingest_integer_columns(base, s0, s1, isz, kind);
   finish_maps();
 }
 
+// Integer and bool frames touch no Python object, so the columns are decoded
+// by a pool of threads with the GIL released.  Each value goes through a small
+// direct-mapped cache in front of the (value -> first-seen id) map.
+void DataframeWrapper::ingest_integer_columns(const char* base, ssize_t s0, ssize_t s1,
+                                              ssize_t isz, char kind) {
+  const size_t rows = num_of_datapoints;
+  std::vector<std::string> errors(num_of_vars);
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    std::vector<uint32_t> ids(rows);
+    struct Slot { int64_t value; uint32_t id; bool used; };
+    for (size_t v = next++; v < num_of_vars; v = next++) {
+      std::vector<std::string> labels;
+      std::unordered_map<int64_t, uint32_t> seen;
+      std::vector<Slot> cache(1024, Slot{0, 0, false});
+      const char* col = base + static_cast<ssize_t>(v) * s1;
+      bool ok = true;
+      for (size_t i = 0; i < rows && ok; ++i) {
+        const int64_t x = read_int(col + static_cast<ssize_t>(i) * s0, kind, isz);
+        Slot& slot = cache[static_cast<uint64_t>(x) & 1023];
+        if (!slot.used || slot.value != x) {
+          auto it = seen.find(x);
+          if (it == seen.end()) {
+            if (labels.size() == 256) {
+              errors[v] = "more than 256 distinct values in column " + col_idx2str[v];
+              ok = false;
+              break;
+            }
+            it = seen.emplace(x, static_cast<uint32_t>(labels.size())).first;
+            labels.push_back(kind == 'b' ? (x ? "True" : "False") : std::to_string(x));
+          }
+          slot = Slot{x, it->second, true};
+        }
+        ids[i] = slot.id;
+      }
+      if (ok) rank_codes(ids, labels, codes.data() + v * rows, val_idx2str[v]);
+    }
+  };
+  {
+    py::gil_scoped_release nogil;
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("OMP_NUM_THREADS")) {
+      const long t = std::strtol(e, nullptr, 10);
+      if (t > 0) nthreads = static_cast<unsigned>(t);
+    }
+    nthreads = std::max(1u, std::min<unsigned>(nthreads, static_cast<unsigned>(num_of_vars)));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+  }
+  for (const auto& e : errors)
+    if (!e.empty()) throw std::invalid_argument(e);
+}
+
+// Data that is already coded: uint8 codes[num_of_vars][num_of_datapoints] with
+// code = rank of the value's label, and the label lists per variable.
 DataframeWrapper::DataframeWrapper(std::vector<uint8_t> c, size_t rows,
                                    std::vector<std::string> columns,
                                    std::vector<std::vector<std::string>> values)
@@ -168,6 +215,13 @@ DataframeWrapper::DataframeWrapper(std::vector<uint8_t> c, size_t rows,
       codes(std::move(c)) {
   if (codes.size() != num_of_vars * num_of_datapoints || val_idx2str.size() != num_of_vars)
     throw std::invalid_argument("coded data does not match its column/value lists");
+  for (size_t v = 0; v < num_of_vars; ++v) {
+    const size_t r = val_idx2str[v].size();
+    if (r == 0 || r > 256) throw std::invalid_argument("a variable needs 1..256 values");
+    const uint8_t* col = codes.data() + v * num_of_datapoints;
+    for (size_t i = 0; i < num_of_datapoints; ++i)
+      if (col[i] >= r) throw std::invalid_argument("code out of range in column " + col_idx2str[v]);
+  }
   finish_maps();
 }
 

@@ -66,6 +66,7 @@ struct DataframeWrapper {
 
  private:
   void finish_maps();
+  void ingest_integer_columns(const char* base, ssize_t s0, ssize_t s1, ssize_t isz, char kind);
   mutable std::shared_ptr<EngineData> engine_;
 };
 

@@ -6,6 +6,8 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <optional>
+
 #include "openbnsl_host.h"
 
 using namespace obnsl;
@@ -21,6 +23,37 @@ PYBIND11_MODULE(openbnsllib, m) {
   auto base = m.def_submodule("base", "Base submodule");
   py::class_<DataframeWrapper>(base, "DataframeWrapper")
       .def(py::init<const py::object&>())
+      // Not in the reference: data that is already coded, e.g. a generator's
+      // uint8 matrix of 10^7 rows that could never pass through Python strings.
+      // codes: uint8 [num_of_vars, num_of_datapoints]; values[v] = labels of
+      // variable v in code order (default: zero-padded decimal codes, cardinality
+      // = largest code + 1).
+      .def_static("from_codes",
+                  [](py::array_t<uint8_t, py::array::c_style | py::array::forcecast> a,
+                     std::vector<std::string> columns,
+                     std::optional<std::vector<std::vector<std::string>>> values) {
+                    if (a.ndim() != 2) throw std::invalid_argument("Input must be a 2D array");
+                    const size_t nv = static_cast<size_t>(a.shape(0)), rows = static_cast<size_t>(a.shape(1));
+                    if (columns.size() != nv)
+                      throw std::invalid_argument("coded data does not match its column/value lists");
+                    std::vector<uint8_t> c(a.data(), a.data() + nv * rows);
+                    std::vector<std::vector<std::string>> vals;
+                    if (values) {
+                      vals = std::move(*values);
+                    } else {
+                      vals.resize(nv);
+                      for (size_t v = 0; v < nv; ++v) {
+                        unsigned top = 0;
+                        for (size_t i = 0; i < rows; ++i) top = std::max<unsigned>(top, c[v * rows + i]);
+                        for (unsigned s = 0; s <= top; ++s) {
+                          std::string t = std::to_string(s);
+                          vals[v].push_back(std::string(3 - t.size(), '0') + t);
+                        }
+                      }
+                    }
+                    return DataframeWrapper(std::move(c), rows, std::move(columns), std::move(vals));
+                  },
+                  py::arg("codes"), py::arg("columns"), py::arg("values") = py::none())
       .def_readonly("num_of_vars", &DataframeWrapper::num_of_vars)
       .def_readonly("num_of_datapoints", &DataframeWrapper::num_of_datapoints)
       .def_readonly("col_idx2str", &DataframeWrapper::col_idx2str)

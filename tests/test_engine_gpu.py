@@ -196,6 +196,11 @@ def test_error_behaviour(engine, golden):
     with pytest.raises(IndexError):
         d.count([1, 99])
     d.close()
+    # a code that is not below the declared cardinality is refused at upload
+    bad = codes.copy()
+    bad[5, 4321] = 2
+    with pytest.raises(ValueError, match="variable 5 has a code"):
+        engine.Data(bad, [2] * 8)
 
 
 def test_alarm_shape_full_size_properties(engine):

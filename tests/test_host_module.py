@@ -69,6 +69,40 @@ def test_dataframe_wrapper_layouts_and_dtypes():
     assert w.val_idx2str == [["False", "True"]] and w.codes.tolist() == [[1, 0, 1]]
 
 
+def test_integer_frames_decode_in_parallel_like_pandas():
+    """Wide integer frame (more columns than decoding threads, signed and
+    unsigned item sizes, negative values): codes and labels as pandas sees them
+    (reference: pytest/base/test_dataframe_wrapper.py:22-52)."""
+    rng = np.random.default_rng(3)
+    for dtype in (np.int8, np.uint8, np.int16, np.uint32, np.int64):
+        lo = -5 if np.issubdtype(dtype, np.signedinteger) else 0
+        raw = rng.integers(lo, lo + 9, size=(5000, 40)).astype(dtype)
+        names = [f"v{j:02d}" for j in range(40)]
+        w = ob.base.DataframeWrapper(pd.DataFrame(raw, columns=names))
+        assert w.num_of_vars == 40 and w.num_of_datapoints == 5000
+        for j in range(40):
+            labels = sorted({str(int(x)) for x in raw[:, j]})
+            assert w.val_idx2str[j] == labels and w.num_of_values[j] == len(labels)
+            assert np.array(labels)[w.codes[j]].tolist() == [str(int(x)) for x in raw[:, j]]
+
+
+def test_from_codes():
+    rng = np.random.default_rng(4)
+    codes = rng.integers(0, 3, size=(4, 1000)).astype(np.uint8)
+    codes[3] = rng.integers(0, 12, size=1000)
+    w = ob.base.DataframeWrapper.from_codes(codes, ["a", "b", "c", "d"])
+    assert w.num_of_values == [3, 3, 3, 12]
+    assert w.val_idx2str[3] == [f"{s:03d}" for s in range(12)]      # order of labels = order of codes
+    assert np.array_equal(w.codes, codes)
+    assert w.col_str2idx == {"a": 0, "b": 1, "c": 2, "d": 3}
+    w = ob.base.DataframeWrapper.from_codes(codes[:2], ["a", "b"], [["lo", "mid", "top"], ["x", "y", "z"]])
+    assert w.val_str2idx[0] == {"lo": 0, "mid": 1, "top": 2}
+    with pytest.raises(ValueError, match="code out of range in column b"):
+        ob.base.DataframeWrapper.from_codes(codes[:2], ["a", "b"], [["lo", "mid", "top"], ["x", "y"]])
+    with pytest.raises(ValueError, match="does not match"):
+        ob.base.DataframeWrapper.from_codes(codes, ["a", "b"])
+
+
 def test_dataframe_wrapper_errors():
     with pytest.raises(ValueError, match="Input must be a pandas dataframe"):
         ob.base.DataframeWrapper([1, 2, 3])
