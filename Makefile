@@ -20,7 +20,7 @@ else
 all: $(ENGINE) oracle
 endif
 
-ENGINE_SRC := openbnsl_amd/csrc/engine.hip openbnsl_amd/csrc/anneal.cpp
+ENGINE_SRC := openbnsl_amd/csrc/engine.hip openbnsl_amd/csrc/anneal.cpp openbnsl_amd/csrc/score_file.cpp
 $(ENGINE): $(ENGINE_SRC) openbnsl_amd/csrc/engine_internal.h include/obnsl_engine.h
 	mkdir -p openbnsl_amd/lib
 	$(HIPCC) $(HIPFLAGS) -Iopenbnsl_amd/csrc -pthread -shared $(ENGINE_SRC) -o $@

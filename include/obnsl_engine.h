@@ -195,6 +195,23 @@ obnsl_status obnsl_anneal_tables(uint32_t num_vars, uint32_t max_parents,
                                  uint64_t seed, uint32_t num_chains, uint32_t* parents_out,
                                  uint32_t* num_parents_out, double* best_score_out);
 
+/* The score tables as a file (host, no GPU).  No counterpart in the reference,
+ * which recomputes every score inside each exhaustive_search call
+ * (src/structure_learning/exhaustive_search.cpp:61-73); consumers of the tables
+ * (obnsl_anneal_tables, the subset dynamic program) can reload them instead.
+ * `tables` as obnsl_anneal_tables takes them.  Little-endian; the layout is
+ * documented in openbnsl_amd/csrc/score_file.cpp. */
+obnsl_status obnsl_scores_save(const char* path, uint32_t num_vars, uint64_t num_rows,
+                               const uint32_t* cardinalities, obnsl_score_kind kind, double ess,
+                               uint32_t max_parents, const double* const* tables);
+/* Header of such a file; every output may be null. */
+obnsl_status obnsl_scores_info(const char* path, uint32_t* num_vars, uint64_t* num_rows,
+                               uint32_t* cardinalities, uint32_t cardinalities_capacity,
+                               obnsl_score_kind* kind, double* ess, uint32_t* max_parents);
+/* The table of subset size k: k * C(num_vars, k) doubles into scores_out. */
+obnsl_status obnsl_scores_load(const char* path, uint32_t k, double* scores_out,
+                               uint64_t capacity);
+
 /* colex rank <-> subset helpers (host, no GPU). */
 uint64_t obnsl_binomial(uint32_t n, uint32_t k);
 obnsl_status obnsl_unrank(uint64_t rank, uint32_t k, uint32_t* var_ids_out);

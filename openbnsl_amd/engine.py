@@ -58,6 +58,12 @@ SIGNATURES = {
                                            ctypes.c_uint64, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32,
                                            _u32p, _u32p, _f64p]),
+    "obnsl_scores_save": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64, _u32p,
+                                         ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
+                                         ctypes.POINTER(_vp)]),
+    "obnsl_scores_info": (ctypes.c_int, [ctypes.c_char_p, _u32p, _u64p, _u32p, ctypes.c_uint32,
+                                         ctypes.POINTER(ctypes.c_int), _f64p, _u32p]),
+    "obnsl_scores_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint32, _f64p, ctypes.c_uint64]),
     "obnsl_binomial": (ctypes.c_uint64, [ctypes.c_uint32, ctypes.c_uint32]),
     "obnsl_unrank": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, _u32p]),
     "obnsl_rank": (ctypes.c_uint64, [_u32p, ctypes.c_uint32]),
@@ -130,6 +136,33 @@ def anneal_tables(n, max_parents, tables, max_iters=10000, init_temp=1.0, coolin
                                    par.ctypes.data_as(_u32p), cnt.ctypes.data_as(_u32p),
                                    ctypes.byref(total)))
     return [par[v, :cnt[v]].tolist() for v in range(n)], total.value
+
+
+def save_scores(path, num_rows, card, kind, ess, tables):
+    """Writes host score tables (tables[k-1]: float64 [C(n,k), k]) to `path`."""
+    card = np.ascontiguousarray(card, dtype=np.uint32)
+    keep = [np.ascontiguousarray(t, dtype=np.float64) for t in tables]
+    arr = (_vp * len(keep))(*[t.ctypes.data for t in keep])
+    _check(lib.obnsl_scores_save(os.fsencode(path), len(card), num_rows, card.ctypes.data_as(_u32p),
+                                 kind, ess, len(keep) - 1, arr))
+
+
+def load_scores(path):
+    """dict(num_vars, num_rows, card, kind, ess, max_parents, tables) from a score-table file."""
+    n, mp, kind = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_int(0)
+    rows, ess = ctypes.c_uint64(0), ctypes.c_double(0.0)
+    p = os.fsencode(path)
+    _check(lib.obnsl_scores_info(p, ctypes.byref(n), ctypes.byref(rows), None, 0, ctypes.byref(kind),
+                                 ctypes.byref(ess), ctypes.byref(mp)))
+    card = np.zeros(n.value, dtype=np.uint32)
+    _check(lib.obnsl_scores_info(p, None, None, card.ctypes.data_as(_u32p), n.value, None, None, None))
+    tables = []
+    for k in range(1, mp.value + 2):
+        t = np.zeros((binomial(n.value, k), k), dtype=np.float64)
+        _check(lib.obnsl_scores_load(p, k, t.ctypes.data_as(_f64p), t.size))
+        tables.append(t)
+    return dict(num_vars=n.value, num_rows=rows.value, card=card, kind=kind.value, ess=ess.value,
+                max_parents=mp.value, tables=tables)
 
 
 class Data:

@@ -131,6 +131,22 @@ PDAG simulated_annealing(const DataframeWrapper& df, const ScoreType& score_type
 std::vector<std::vector<double>> score_tables(const DataframeWrapper& df,
                                               const ScoreType& score_type, size_t max_parents);
 
+// Score tables on disk (obnsl_scores_save / obnsl_scores_load).
+void save_score_tables(const std::string& path, const DataframeWrapper& df,
+                       const ScoreType& score_type, size_t max_parents);
+struct LoadedScores {
+  size_t num_of_vars = 0, num_of_datapoints = 0, max_parents = 0;
+  std::vector<size_t> num_of_values;
+  ScoreType score_type;
+  std::vector<std::vector<double>> tables;
+};
+LoadedScores load_score_tables(const std::string& path);
+
+// The annealing chains on given score tables (host only).
+PDAG anneal_from_tables(size_t n, size_t max_parents, const std::vector<std::vector<double>>& tables,
+                        size_t max_iters, double init_temp, double cooling_rate,
+                        bool is_deterministic, uint64_t seed, size_t num_chains);
+
 // The dynamic program of the search on given score tables (host only).
 PDAG search_from_tables(size_t n, size_t max_parents,
                         const std::vector<std::vector<double>>& tables, double* total_score);

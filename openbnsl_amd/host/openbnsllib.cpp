@@ -119,6 +119,20 @@ PYBIND11_MODULE(openbnsllib, m) {
   // on given tables (host only; lets the dynamic program be tested without a GPU).
   sl.def("score_tables", &score_tables, py::arg("df"), py::arg("score_type"),
          py::arg("max_parents"));
+  sl.def("save_score_tables", &save_score_tables, py::arg("path"), py::arg("df"),
+         py::arg("score_type"), py::arg("max_parents"));
+  py::class_<LoadedScores>(sl, "LoadedScores")
+      .def_readonly("num_of_vars", &LoadedScores::num_of_vars)
+      .def_readonly("num_of_datapoints", &LoadedScores::num_of_datapoints)
+      .def_readonly("max_parents", &LoadedScores::max_parents)
+      .def_readonly("num_of_values", &LoadedScores::num_of_values)
+      .def_readonly("score_type", &LoadedScores::score_type)
+      .def_readonly("tables", &LoadedScores::tables);
+  sl.def("load_score_tables", &load_score_tables, py::arg("path"));
+  sl.def("anneal_from_tables", &anneal_from_tables, py::arg("num_of_vars"), py::arg("max_parents"),
+         py::arg("tables"), py::arg("max_iters") = 10000, py::arg("init_temp") = 1.0,
+         py::arg("cooling_rate") = 0.9995, py::arg("is_deterministic") = false,
+         py::arg("seed") = 0, py::arg("num_chains") = 0);
   sl.def("search_from_tables",
          [](size_t n, size_t max_parents, const std::vector<std::vector<double>>& tables) {
            if (n == 0 || n > 30 || max_parents > n - 1 || tables.size() != max_parents + 1)

@@ -229,4 +229,71 @@ PDAG simulated_annealing(const DataframeWrapper& df, const ScoreType& score_type
   return g;
 }
 
+PDAG anneal_from_tables(size_t n, size_t max_parents, const std::vector<std::vector<double>>& tables,
+                        size_t max_iters, double init_temp, double cooling_rate,
+                        bool is_deterministic, uint64_t seed, size_t num_chains) {
+  if (max_parents >= n) throw std::invalid_argument("max_parents out of range");
+  if (tables.size() != max_parents + 1)
+    throw std::invalid_argument("one score table per subset size 1..max_parents+1 is needed");
+  std::vector<const double*> ptrs;
+  for (size_t k = 1; k <= max_parents + 1; ++k) {
+    if (tables[k - 1].size() != obnsl_binomial(static_cast<uint32_t>(n), static_cast<uint32_t>(k)) * k)
+      throw std::invalid_argument("score table of the wrong size");
+    ptrs.push_back(tables[k - 1].data());
+  }
+  const size_t width = max_parents ? max_parents : 1;
+  std::vector<uint32_t> parents(n * width, 0), count(n, 0);
+  {
+    py::gil_scoped_release nogil;
+    check(obnsl_anneal_tables(static_cast<uint32_t>(n), static_cast<uint32_t>(max_parents),
+                              ptrs.data(), max_iters, init_temp, cooling_rate,
+                              is_deterministic ? 1 : 0, seed, static_cast<uint32_t>(num_chains),
+                              parents.data(), count.data(), nullptr));
+  }
+  PDAG g(n);
+  for (size_t v = 0; v < n; ++v)
+    for (size_t j = 0; j < count[v]; ++j) g.add_edge(parents[v * width + j], v);
+  return g;
+}
+
+void save_score_tables(const std::string& path, const DataframeWrapper& df,
+                       const ScoreType& score_type, size_t max_parents) {
+  if (df.num_of_vars == 0 || max_parents > df.num_of_vars - 1)
+    throw std::invalid_argument("max_parents must be in [0, num_of_vars-1]");
+  const auto tables = score_tables(df, score_type, max_parents);
+  std::vector<const double*> ptrs;
+  for (const auto& t : tables) ptrs.push_back(t.data());
+  std::vector<uint32_t> card(df.num_of_values.begin(), df.num_of_values.end());
+  check(obnsl_scores_save(path.c_str(), static_cast<uint32_t>(df.num_of_vars), df.num_of_datapoints,
+                          card.data(), score_kind(score_type), score_ess(score_type),
+                          static_cast<uint32_t>(max_parents), ptrs.data()));
+}
+
+LoadedScores load_score_tables(const std::string& path) {
+  LoadedScores out;
+  uint32_t n = 0, mp = 0;
+  uint64_t rows = 0;
+  obnsl_score_kind kind = OBNSL_SCORE_BDEU;
+  double ess = 1.0;
+  check(obnsl_scores_info(path.c_str(), &n, &rows, nullptr, 0, &kind, &ess, &mp));
+  std::vector<uint32_t> card(n);
+  check(obnsl_scores_info(path.c_str(), nullptr, nullptr, card.data(), n, nullptr, nullptr, nullptr));
+  out.num_of_vars = n;
+  out.num_of_datapoints = rows;
+  out.max_parents = mp;
+  out.num_of_values.assign(card.begin(), card.end());
+  switch (kind) {
+    case OBNSL_SCORE_BDEU: out.score_type = BDeu(ess); break;
+    case OBNSL_SCORE_K2: out.score_type = K2{}; break;
+    case OBNSL_SCORE_BIC: out.score_type = BIC{}; break;
+    default: out.score_type = AIC{}; break;
+  }
+  out.tables.resize(mp + 1);
+  for (uint32_t k = 1; k <= mp + 1; ++k) {
+    out.tables[k - 1].resize(obnsl_binomial(n, k) * k);
+    check(obnsl_scores_load(path.c_str(), k, out.tables[k - 1].data(), out.tables[k - 1].size()));
+  }
+  return out;
+}
+
 }  // namespace obnsl

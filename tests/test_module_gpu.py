@@ -167,3 +167,22 @@ def test_exhaustive_search_error_paths(ob):
     with pytest.raises(ValueError, match="dynamic program"):
         d.exhaustive_search(2)
     d.close()
+
+
+def test_score_tables_saved_from_the_gpu_reload_exactly(ob, tmp_path):
+    """save_score_tables writes what score_tables returns; a search on the
+    reloaded tables gives the graph of the search on the device."""
+    from openbnsl_amd import synth
+    codes, card, _, _ = synth.random_bn([2, 3, 2, 4, 3, 2, 3, 2, 2, 3], 5000, seed=8, n_arcs=12)
+    names = [f"c{v:02d}" for v in range(10)]
+    w = ob.base.DataframeWrapper.from_codes(codes, names)
+    path = str(tmp_path / "t.obnsl")
+    ob.structure_learning.save_score_tables(path, w, ob.score.BDeu(1.0), 3)
+    ld = ob.structure_learning.load_score_tables(path)
+    direct = ob.structure_learning.score_tables(w, ob.score.BDeu(1.0), 3)
+    assert ld.num_of_datapoints == 5000 and ld.num_of_values == card.tolist()
+    for a, b in zip(direct, ld.tables):
+        assert np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+    g1, _ = ob.structure_learning.search_from_tables(10, 3, ld.tables)
+    g2 = ob.structure_learning.exhaustive_search(w, ob.score.BDeu(1.0), 3)
+    assert all(g1.has_edge(p, v) == g2.has_edge(p, v) for p in range(10) for v in range(10))
