@@ -150,6 +150,14 @@ obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
 obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_scores,
                                        uint32_t max_parents, double* d_out);
 
+/* The combine step after ranks have all-gathered their obnsl_best_parents_device
+ * records: d_parts (device) = `world` records of 3 * num_vars doubles, rank
+ * after rank; d_out (device, 3 * num_vars doubles) = per node the best of them
+ * by the same rule (score, then fewer parents, then lower rank).  Asynchronous
+ * on the data set's stream.  No counterpart in the reference (single process). */
+obnsl_status obnsl_combine_best_device(obnsl_data* d, const double* d_parts, uint32_t world,
+                                       double* d_out);
+
 /* Replaces exhaustive_search(df, score_type, max_parents, is_deterministic)
  * (src/structure_learning/exhaustive_search.cpp:14-165) end to end on the
  * device: the score tables of sizes 1..max_parents+1, then the subset dynamic

@@ -852,6 +852,28 @@ __global__ __launch_bounds__(256) void best_parents_kernel(
 }
 
 // keys[0..n) = 0 (below every ordered score), ids[0..n) = all ones (above every id)
+// Per node, the best of `world` records (score, number of parents, rank of the
+// parent set): highest score, then fewer parents, then lower rank -- the rule
+// best_parents_kernel applies inside one shard.
+__global__ void best_combine_kernel(const double* __restrict__ parts, uint32_t world, uint32_t n,
+                                    double* __restrict__ out) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  double bs = parts[(size_t)v * 3], bz = parts[(size_t)v * 3 + 1], br = parts[(size_t)v * 3 + 2];
+  for (uint32_t w = 1; w < world; ++w) {
+    const double* p = parts + ((size_t)w * n + v) * 3;
+    const double s = p[0], z = p[1], r = p[2];
+    if (s > bs || (s == bs && (z < bz || (z == bz && r < br)))) {
+      bs = s;
+      bz = z;
+      br = r;
+    }
+  }
+  out[(size_t)v * 3] = bs;
+  out[(size_t)v * 3 + 1] = bz;
+  out[(size_t)v * 3 + 2] = br;
+}
+
 __global__ void best_init_kernel(unsigned long long* keys, unsigned long long* ids, uint32_t n) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) {
@@ -1032,6 +1054,7 @@ struct Plan {
   DevBuf<uint32_t> red;
   DevBuf<uint64_t> rowoff;      // by colex rank of the kr-subset
   uint64_t counted_epoch = 0;   // data epoch the counters in `red` belong to
+  int pending_lane = -1;        // side lane still producing `red` (-1: none, or already joined)
   uint64_t total_items = 0;
   // per-table functional G[colex rank] of this plan's tables (see score_reduced_kernel)
   DevBuf<double> G;
@@ -1055,13 +1078,15 @@ struct obnsl_data {
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, bool>, std::unique_ptr<Plan>> plans;
   std::map<std::tuple<uint32_t, uint64_t, uint64_t>, std::vector<std::unique_ptr<HistBatch>>> hist_plans;
   uint64_t epoch = 1;                                 // bumped whenever the planes are rebuilt
-  hipStream_t side = nullptr;                         // second stream for obnsl_precount (default priority)
-  hipEvent_t side_fork = nullptr, side_join = nullptr;
-  bool count_on_side = false;                         // launch_count targets `side` instead of `stream`
-  const void* side_pending = nullptr;                 // plan whose counts are still being produced on `side`
+  // obnsl_precount counts on two extra streams ("lanes", default priority): lane 0
+  // the largest size, lane 1 the small sizes below the second largest
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t side_fork = nullptr, side_join[2] = {nullptr, nullptr};
+  int count_lane = -1;                                // launch_count targets side[count_lane] (-1: `stream`)
+  std::vector<Plan*> lane_plans[2];                   // plans whose counts a lane is still producing
   // per ess: lgamma(ess / c) for c = 1..REDUCED_MAX_CELLS (index c), from the host's libm
   std::map<double, std::unique_ptr<DevBuf<double>>> lg_alpha;
-  hipStream_t count_stream() const { return count_on_side ? side : stream; }
+  hipStream_t count_stream() const { return count_lane >= 0 ? side[count_lane] : stream; }
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // around each bit-GEMM launch
   std::vector<uint32_t> ev_size;                      // subset size of each pending pair
   uint32_t ev_used = 0;                               // pending pairs
@@ -1073,8 +1098,10 @@ struct obnsl_data {
       (void)hipEventDestroy(e.second);
     }
     if (side_fork) (void)hipEventDestroy(side_fork);
-    if (side_join) (void)hipEventDestroy(side_join);
-    if (side) (void)hipStreamDestroy(side);
+    for (int l = 0; l < 2; ++l) {
+      if (side_join[l]) (void)hipEventDestroy(side_join[l]);
+      if (side[l]) (void)hipStreamDestroy(side[l]);
+    }
   }
 };
 
@@ -1198,15 +1225,67 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     cum[g + 1] = cum[g] + M * ncols_below[rsub[g][0]];
   }
   const uint64_t total_cost = cum[rsub.size()];
-  // shard = contiguous run of row groups with equal share of the counters
+  // shard = contiguous run of row groups.  What a shard costs is what its
+  // launch computes: row tiles of `edge` rows (the last one padded) times the
+  // column limit of each tile's last row rounded up to the 16-column groups the
+  // kernel skips by.  The cuts minimise the most expensive shard (a shard of a
+  // few very wide rows pays a whole row tile for them, so equal counter shares
+  // are not equal work).
   size_t g_lo = 0, g_hi = rsub.size();
-  if (nshards > 1) {
-    const uint64_t lo_c = total_cost / nshards * shard + std::min<uint64_t>(shard, total_cost % nshards);
-    const uint64_t hi_c = total_cost / nshards * (shard + 1) + std::min<uint64_t>(shard + 1, total_cost % nshards);
-    g_lo = std::lower_bound(cum.begin(), cum.end() - 1, lo_c) - cum.begin();
-    g_hi = std::lower_bound(cum.begin(), cum.end() - 1, hi_c) - cum.begin();
-    if (shard == nshards - 1) g_hi = rsub.size();
-    if (shard == 0) g_lo = 0;
+  if (nshards > 1 && !rsub.empty()) {
+    std::vector<uint64_t> row0(rsub.size() + 1, 0);
+    for (size_t g = 0; g < rsub.size(); ++g) row0[g + 1] = row0[g] + Ms[g];
+    const uint64_t edge = (total_cost / nshards) / (128 * 128) < 2048 ? 64 : 128;
+    auto range_cost = [&](size_t lo, size_t hi) {
+      uint64_t c = 0;
+      size_t g = lo;
+      for (uint64_t r = row0[lo]; r < row0[hi]; r += edge) {
+        const uint64_t last = std::min<uint64_t>(r + edge, row0[hi]) - 1;
+        while (row0[g + 1] <= last) ++g;
+        c += edge * (((uint64_t)ncols_below[rsub[g][0]] + 15) / 16 * 16);
+      }
+      return c;
+    };
+    // cuts[s] = first group of shard s under bottleneck B; false if B is too small
+    auto cut = [&](uint64_t B, std::vector<size_t>& cuts) {
+      cuts.assign(nshards + 1, rsub.size());
+      size_t lo = 0;
+      for (uint32_t sh = 0; sh < nshards; ++sh) {
+        cuts[sh] = lo;
+        if (sh + 1 == nshards) return range_cost(lo, rsub.size()) <= B;
+        size_t a = lo, b = rsub.size();  // largest hi with cost(lo, hi) <= B
+        while (a < b) {
+          const size_t mid = (a + b + 1) / 2;
+          if (range_cost(lo, mid) <= B) a = mid; else b = mid - 1;
+        }
+        lo = a;
+      }
+      return true;
+    };
+    std::vector<size_t> cuts, best_cuts;
+    uint64_t lo_b = 0, hi_b = range_cost(0, rsub.size());
+    if (row0.back() / edge > (1u << 16)) {
+      // very many row tiles: equal shares of the counters are close enough
+      best_cuts.assign(nshards + 1, rsub.size());
+      for (uint32_t sh = 0; sh < nshards; ++sh) {
+        const uint64_t c = total_cost / nshards * sh + std::min<uint64_t>(sh, total_cost % nshards);
+        best_cuts[sh] = sh == 0 ? 0 : std::lower_bound(cum.begin(), cum.end() - 1, c) - cum.begin();
+      }
+      lo_b = hi_b;
+    } else {
+      cut(hi_b, best_cuts);
+    }
+    while (lo_b < hi_b) {
+      const uint64_t mid = lo_b + (hi_b - lo_b) / 2;
+      if (cut(mid, cuts)) {
+        hi_b = mid;
+        best_cuts = cuts;
+      } else {
+        lo_b = mid + 1;
+      }
+    }
+    g_lo = best_cuts[shard];
+    g_hi = best_cuts[shard + 1];
   }
 
   std::vector<uint64_t> rowoff;
@@ -1354,7 +1433,11 @@ obnsl_status launch_count(obnsl_data* d, const Plan* plan, const Batch* b, uint3
     const char* e = std::getenv("OBNSL_TARGET_WGS");
     return e ? (uint32_t)std::atoi(e) : 8192u;
   }();
-  const uint32_t max_split = std::max<uint32_t>(1, steps_total / 8);
+  static const uint32_t min_sps = [] {
+    const char* e = std::getenv("OBNSL_MIN_SPS");
+    return e ? std::max(1u, (uint32_t)std::atoi(e)) : 8u;
+  }();
+  const uint32_t max_split = std::max<uint32_t>(1, steps_total / min_sps);
   if (b->nitems < want) ksplit = std::min<uint32_t>((want + b->nitems - 1) / b->nitems, max_split);
   const uint32_t sps = (steps_total + ksplit - 1) / ksplit;
   ksplit = (steps_total + sps - 1) / sps;
@@ -1392,19 +1475,25 @@ obnsl_status launch_count(obnsl_data* d, const Plan* plan, const Batch* b, uint3
   return OBNSL_OK;
 }
 
-// Makes the main stream wait for the side stream's outstanding count launch.
-obnsl_status join_side(obnsl_data* d) {
-  if (d->side_pending) {
-    HIP_TRY(hipStreamWaitEvent(d->stream, d->side_join, 0));
-    d->side_pending = nullptr;
+// Makes the main stream wait for one lane's outstanding count launches.
+obnsl_status join_lane(obnsl_data* d, int lane) {
+  if (!d->lane_plans[lane].empty()) {
+    HIP_TRY(hipStreamWaitEvent(d->stream, d->side_join[lane], 0));
+    for (Plan* p : d->lane_plans[lane]) p->pending_lane = -1;
+    d->lane_plans[lane].clear();
   }
   return OBNSL_OK;
+}
+
+obnsl_status join_side(obnsl_data* d) {
+  obnsl_status st = join_lane(d, 0);
+  return st == OBNSL_OK ? join_lane(d, 1) : st;
 }
 
 // Reduced mode: make plan->red hold the counts of the current planes.
 obnsl_status ensure_counts(obnsl_data* d, Plan* plan) {
   if (plan->counted_epoch == d->epoch) {
-    if (d->side_pending == plan) return join_side(d);
+    if (plan->pending_lane >= 0) return join_lane(d, plan->pending_lane);
     return OBNSL_OK;
   }
   obnsl_status st = launch_count(d, plan, plan->batches[0].get(), plan->red.p);
@@ -1942,16 +2031,19 @@ obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32
   // below it are all counted whole (none of them is "the sharded top size")
   const bool top_is_requested = whole_request && top_size == kmax;
   kmax = top_size;
-  if (!d->side) {
-    HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+  if (!d->side[0]) {
     HIP_TRY(hipEventCreateWithFlags(&d->side_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&d->side_join, hipEventDisableTiming));
+    for (int l = 0; l < 2; ++l) {
+      HIP_TRY(hipStreamCreateWithFlags(&d->side[l], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&d->side_join[l], hipEventDisableTiming));
+    }
   }
-  // The top size is counted on the side stream, the sizes below it (largest
-  // first) on the main stream, so that their scorers -- queued on the main stream
-  // by the obnsl_score_all calls that follow -- run while the top size is still
-  // being counted.  The main stream joins the side stream where the top size's
-  // counts are first used (ensure_counts) or before the planes change (run_pack).
+  // The top size is counted on lane 0, the size below it on the main stream and
+  // the smaller ones on lane 1, so that the scorers of the lower sizes -- queued
+  // on the main stream by the obnsl_score_all calls that follow -- run while the
+  // top size is still being counted.  The main stream joins a lane where one of
+  // its count tables is first used (ensure_counts) or before the planes change
+  // (run_pack).
   st = join_side(d);
   if (st != OBNSL_OK) return st;
   Plan* top = nullptr;
@@ -1961,22 +2053,42 @@ obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32
     st = build_plan(d, kmax, shard, num_shards, true, &top);
     if (st != OBNSL_OK) return st;
   }
+  // fork: the lanes start after everything queued so far (the pack)
+  HIP_TRY(hipEventRecord(d->side_fork, d->stream));
   if (top->counted_epoch != d->epoch) {
-    // fork: the side stream starts after everything queued so far (the pack)
-    HIP_TRY(hipEventRecord(d->side_fork, d->stream));
-    HIP_TRY(hipStreamWaitEvent(d->side, d->side_fork, 0));
-    d->count_on_side = true;
+    HIP_TRY(hipStreamWaitEvent(d->side[0], d->side_fork, 0));
+    d->count_lane = 0;
     st = ensure_counts(d, top);
-    d->count_on_side = false;
+    d->count_lane = -1;
     if (st != OBNSL_OK) return st;
-    HIP_TRY(hipEventRecord(d->side_join, d->side));
-    d->side_pending = top;
+    HIP_TRY(hipEventRecord(d->side_join[0], d->side[0]));
+    top->pending_lane = 0;
+    d->lane_plans[0].push_back(top);
   }
-  for (uint32_t j = kmax - 1; j >= 1 && st == OBNSL_OK; --j) {
+  // second largest size on the main stream; the small sizes below it are short,
+  // latency-bound launches and run beside it on lane 1
+  if (kmax >= 2) {
+    Plan* full = nullptr;
+    st = build_plan(d, kmax - 1, 0, 1, true, &full);
+    if (st == OBNSL_OK) st = ensure_counts(d, full);
+    if (st != OBNSL_OK) return st;
+  }
+  bool lane1_used = false;
+  for (uint32_t j = kmax >= 2 ? kmax - 2 : 0; j >= 1; --j) {
     Plan* full = nullptr;
     st = build_plan(d, j, 0, 1, true, &full);
-    if (st == OBNSL_OK) st = ensure_counts(d, full);
+    if (st != OBNSL_OK) return st;
+    if (full->counted_epoch == d->epoch) continue;
+    if (!lane1_used) HIP_TRY(hipStreamWaitEvent(d->side[1], d->side_fork, 0));
+    lane1_used = true;
+    d->count_lane = 1;
+    st = ensure_counts(d, full);
+    d->count_lane = -1;
+    if (st != OBNSL_OK) return st;
+    full->pending_lane = 1;
+    d->lane_plans[1].push_back(full);
   }
+  if (lane1_used) HIP_TRY(hipEventRecord(d->side_join[1], d->side[1]));
   return st;
 }
 
@@ -2102,6 +2214,17 @@ obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_sco
   if (st != OBNSL_OK) return st;
   hipLaunchKernelGGL(best_decode_kernel, dim3((d->n + 255) / 256), dim3(256), 0, d->stream,
                      d->best_key.p, d->best_key.p + d->n, d->n, d_out);
+  HIP_TRY(hipGetLastError());
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_combine_best_device(obnsl_data* d, const double* d_parts, uint32_t world,
+                                       double* d_out) {
+  if (!d || !d_parts || !d_out || world == 0) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  obnsl_status st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  hipLaunchKernelGGL(best_combine_kernel, dim3((d->n + 255) / 256), dim3(256), 0, d->stream, d_parts,
+                     world, d->n, d_out);
   HIP_TRY(hipGetLastError());
   return OBNSL_OK;
 }

@@ -9,7 +9,6 @@ device score tables, the stream and torch.distributed; every kernel launched is
 the engine's (include/obnsl_engine.h)."""
 import numpy as np
 
-from . import distributed as obd
 from . import engine
 
 
@@ -34,6 +33,7 @@ class HotPath:
         self.best = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
         self.gathered = (torch.empty((world, self.n, 3), dtype=torch.float64, device=self.dev)
                          if world > 1 else None)
+        self.combined = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
 
     def step(self):
         """One pass, queued asynchronously on the current stream (no host
@@ -53,12 +53,14 @@ class HotPath:
         import torch.distributed as dist
         if dist.get_backend() == "nccl":
             dist.all_gather_into_tensor(self.gathered.view(-1), self.best.view(-1))
-            return obd.combine_best_device(self.gathered)
-        # gloo: host tensors only
-        mine = self.best.cpu()
-        out = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype)
-        dist.all_gather_into_tensor(out.view(-1), mine.view(-1))
-        return obd.combine_best_device(out).to(self.dev)
+        else:
+            # gloo: host tensors only
+            mine = self.best.cpu()
+            out = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype)
+            dist.all_gather_into_tensor(out.view(-1), mine.view(-1))
+            self.gathered.copy_(out)
+        d.combine_best_device(self.gathered.data_ptr(), self.world, self.combined.data_ptr())
+        return self.combined
 
     @staticmethod
     def to_host(best):

@@ -310,3 +310,28 @@ def test_largest_subset_sizes_and_tiny_problems(engine):
         want, wtotal = oracle.exhaustive_search(codes, card, len(cards) - 1)
         assert abs(total - wtotal) <= 1e-9 * abs(wtotal)
         d.close()
+
+
+def test_combine_kernel_applies_the_tie_rule(engine):
+    """obnsl_combine_best_device against the numpy statement of the same rule
+    (highest score, then fewer parents, then lower rank), with ties forced."""
+    import torch
+    from openbnsl_amd import distributed as obd
+    rng = np.random.default_rng(2)
+    n, world = 8, 5
+    codes = rng.integers(0, 2, size=(n, 256)).astype(np.uint8)
+    d = engine.Data(codes, [2] * n)
+    parts = np.zeros((world, n, 3))
+    parts[:, :, 0] = -rng.integers(1, 4, size=(world, n)).astype(np.float64)   # many equal scores
+    parts[:, :, 1] = rng.integers(0, 3, size=(world, n))
+    parts[:, :, 2] = rng.integers(0, 5, size=(world, n))
+    parts[1, 3, 0] = -np.inf                                                     # a shard without this node
+    dev = torch.from_numpy(parts).cuda()
+    out = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+    d.set_stream(torch.cuda.current_stream().cuda_stream)
+    d.combine_best_device(dev.data_ptr(), world, out.data_ptr())
+    torch.cuda.synchronize()
+    sc, sz, rk = obd.combine_best(parts)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, 0], sc) and np.array_equal(got[:, 1], sz) and np.array_equal(got[:, 2], rk)
+    d.close()

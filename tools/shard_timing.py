@@ -28,6 +28,7 @@ best = torch.empty((d.n, 3), dtype=torch.float64, device="cuda")
 for world in [int(x) for x in args.worlds.split(",")]:
     worst = 0.0
     per = []
+    gem = []
     for rank in range(world):
         for t in tabs:
             t.fill_(float("-inf"))
@@ -42,10 +43,15 @@ for world in [int(x) for x in args.worlds.split(",")]:
         for _ in range(3):
             step()
         torch.cuda.synchronize()
+        for k in range(1, mp + 2):
+            d.kernel_time(k, reset=True)
         t0 = time.perf_counter()
         for _ in range(args.reps):
             step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / args.reps * 1e3
         per.append(ms)
+        gem.append(" ".join(f"{d.kernel_time(k)[0] / max(1, d.kernel_time(k)[1]):.3f}" for k in range(1, mp + 2)))
+    for r, g in enumerate(gem):
+        print(f"  rank {r}: count-kernel ms by size: {g}")
     print(f"world {world}: per-rank ms/step {' '.join(f'{x:.3f}' for x in per)}  max {max(per):.3f}", flush=True)
