@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="alarm37_1e6_bdeu_mp3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-hot-path", action="store_true",
+                    help="skip the exhaustive-search / annealing wall-clock legs and the CPU baseline "
+                         "(profiling runs: every kernel launch then belongs to the timed pass)")
     args = ap.parse_args()
 
     import torch
@@ -281,10 +284,10 @@ def main():
                      "kernel_ms": kernel_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch},
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.only_hot_path:
         out["exhaustive_search"] = exhaustive_search_wallclock(engine, not args.no_cpu_baseline)
         out["simulated_annealing"] = simulated_annealing_wallclock(engine, data, not args.no_cpu_baseline)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.only_hot_path:
         try:
             base, omp = cpu_baseline(codes, card, names, mp)
             out["cpu_baseline"] = base

@@ -8,10 +8,10 @@ tag=${1:-prof}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace -- \
-  python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_trace.log 2>&1
+  python3 bench.py --steps 20 --warmup 3 --only-hot-path > gpurun_out/${tag}_trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- \
-  python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_fetch.log 2>&1
+  python3 bench.py --steps 3 --warmup 1 --only-hot-path > gpurun_out/${tag}_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- \
-  python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_write.log 2>&1
+  python3 bench.py --steps 3 --warmup 1 --only-hot-path > gpurun_out/${tag}_write.log 2>&1
 grep '^{' gpurun_out/${tag}_trace.log > gpurun_out/${tag}_bench_under_trace.json
 echo profiled

@@ -17,7 +17,9 @@ workload = sys.argv[4] if len(sys.argv) > 4 else "alarm37_1e6_bdeu_mp3"
 
 
 def one(pattern):
-    return glob.glob(pattern)[0]
+    # gpurun_out/ keeps the files of earlier runs: take the newest
+    import os
+    return max(glob.glob(pattern), key=os.path.getmtime)
 
 
 shutil.copy(one(f"gpurun_out/{tag}_trace/*/*kernel_stats.csv"), f"profiles/{name}_bench_kernel_stats.csv")
