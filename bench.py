@@ -251,7 +251,7 @@ def main():
     # HBM traffic of that kernel: not measurable from inside this process (PMC
     # counters need a rocprofv3 pass); taken from the committed pass over this
     # same command when the workload matches, else null
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu = None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc_path) and world == 1:
         with open(pmc_path) as f:
@@ -259,6 +259,16 @@ def main():
         if pmc.get("workload") == args.workload:
             traffic = pmc["traffic_bytes_per_launch"] / 1e9
             traffic_src = "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, GB per launch)"
+            instr = pmc.get("instructions_per_launch", {}).get("SQ_INSTS_VALU")
+            if instr and kernel_ms > 0:
+                # what actually bounds the kernel: vector-ALU issue.  Its instruction stream is
+                # and/popcount pairs, 2 + 4 cycles per wave64 pair per SIMD (measured issue costs,
+                # profiles/r1h_ubench_valu.txt); peak = 1024 SIMDs at the 2.4 GHz maximum clock.
+                peak = 1024 * 2.4e9 / 3.0
+                valu = {"bound": "valu-issue", "wave_instructions_per_launch": instr,
+                        "achieved": instr / (kernel_ms * 1e-3), "peak": peak,
+                        "unit": "wave64 instructions/s", "frac": instr / (kernel_ms * 1e-3) / peak,
+                        "source": "SQ_INSTS_VALU from profiles/pmc_summary.json; live kernel time"}
 
     out = {
         "metric": "parent-set scores/sec",
@@ -284,6 +294,8 @@ def main():
                      "kernel_ms": kernel_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch},
     }
+    if valu:
+        out["roofline_valu"] = valu
     if rank == 0 and world == 1 and not args.only_hot_path:
         out["exhaustive_search"] = exhaustive_search_wallclock(engine, not args.no_cpu_baseline)
         out["simulated_annealing"] = simulated_annealing_wallclock(engine, data, not args.no_cpu_baseline)

@@ -41,6 +41,16 @@ shutil.copy(fetch_csv, f"profiles/{name}_pmc_fetch_size.csv")
 shutil.copy(write_csv, f"profiles/{name}_pmc_write_size.csv")
 f_kib, nf = per_launch(fetch_csv, "FETCH_SIZE")
 w_kib, nw = per_launch(write_csv, "WRITE_SIZE")
+sq = {}
+sq_hits = glob.glob(f"gpurun_out/{tag}_sq/*/*counter_collection.csv")
+if sq_hits:
+    sq_csv = one(f"gpurun_out/{tag}_sq/*/*counter_collection.csv")
+    shutil.copy(sq_csv, f"profiles/{name}_pmc_sq.csv")
+    for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT"):
+        try:
+            sq[c] = per_launch(sq_csv, c)[0]
+        except ZeroDivisionError:
+            pass
 summary = {
     "workload": workload,
     "kernel": dominant,
@@ -48,6 +58,7 @@ summary = {
     "fetch_bytes_per_launch_corrected": f_kib * 1024 * 2,
     "write_bytes_per_launch": w_kib * 1024,
     "traffic_bytes_per_launch": f_kib * 1024 * 2 + w_kib * 1024,
+    "instructions_per_launch": sq,
     "note": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/{name}_pmc_*_size.csv); "
             "counters are in KiB; FETCH_SIZE doubled (gfx950 reports half the bytes of 16-B-per-lane coalesced loads)",
 }
