@@ -269,15 +269,13 @@ obnsl_status anneal(const Settings& cfg, ScoreSource& src, uint64_t seed, uint32
   return OBNSL_OK;
 }
 
-obnsl_status check_common(uint32_t n, uint32_t max_parents, uint64_t max_iters, double init_temp,
-                          const void* parents_out, const void* num_parents_out) {
+obnsl_status check_common(uint32_t n, uint32_t max_parents, const void* parents_out,
+                          const void* num_parents_out) {
   if (!parents_out || !num_parents_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
   if (n == 0 || max_parents >= n)  // reference: :109-111
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents out of range");
   if (max_parents + 1 > OBNSL_MAX_SUBSET)
     return fail(OBNSL_ERR_UNSUPPORTED, "max_parents + 1 exceeds OBNSL_MAX_SUBSET");
-  (void)max_iters;
-  (void)init_temp;
   return OBNSL_OK;
 }
 
@@ -297,7 +295,7 @@ obnsl_status obnsl_anneal_tables(uint32_t num_vars, uint32_t max_parents,
                                  double init_temp, double cooling_rate, int is_deterministic,
                                  uint64_t seed, uint32_t num_chains, uint32_t* parents_out,
                                  uint32_t* num_parents_out, double* best_score_out) {
-  obnsl_status st = check_common(num_vars, max_parents, max_iters, init_temp, parents_out, num_parents_out);
+  obnsl_status st = check_common(num_vars, max_parents, parents_out, num_parents_out);
   if (st != OBNSL_OK) return st;
   if (!tables) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
   for (uint32_t k = 1; k <= max_parents + 1; ++k)
@@ -333,7 +331,7 @@ obnsl_status obnsl_simulated_annealing(obnsl_data* d, obnsl_score_kind kind, dou
   uint32_t n = 0;
   obnsl_status st = obnsl_data_shape(d, &rows, &n);
   if (st != OBNSL_OK) return st;
-  st = check_common(n, max_parents, max_iters, init_temp, parents_out, num_parents_out);
+  st = check_common(n, max_parents, parents_out, num_parents_out);
   if (st != OBNSL_OK) return st;
   if (kind != OBNSL_SCORE_BDEU && kind != OBNSL_SCORE_BIC)
     return fail(OBNSL_ERR_UNSUPPORTED, "Unsupported score type.");
