@@ -133,7 +133,7 @@ def test_sharded_scores_cover_everything_once(engine):
         want = oracle.score_all(codes, card, k, nthreads=4)
         T = d.num_subsets(k)
         filled = torch.zeros(T * k, dtype=torch.float64, device="cuda")
-        for nsh in (3,):
+        for nsh in (2, 3, 8, 32):     # 32: more shards than row groups (empty shards)
             parts = []
             for sh in range(nsh):
                 buf = torch.full((T * k,), float("-inf"), dtype=torch.float64, device="cuda")
@@ -335,3 +335,32 @@ def test_combine_kernel_applies_the_tie_rule(engine):
     got = out.cpu().numpy()
     assert np.array_equal(got[:, 0], sc) and np.array_equal(got[:, 1], sz) and np.array_equal(got[:, 2], rk)
     d.close()
+
+
+def test_randomised_sweep_against_the_oracle(engine):
+    """Seeded random shapes: 1..6 states per variable (constant columns
+    included), row counts around the 32-row word and 2048-row padding edges,
+    BDeu with random ess and BIC, every subset size the data set allows up to 5;
+    exhaustive search on the same data."""
+    import oracle
+    rng = np.random.default_rng(2024)
+    edge_rows = [1, 2, 31, 32, 33, 63, 65, 2047, 2048, 2049, 4097]
+    for case in range(14):
+        n = int(rng.integers(2, 8))
+        card = rng.integers(1, 7, size=n).astype(np.uint32)
+        N = int(edge_rows[case]) if case < len(edge_rows) else int(rng.integers(100, 6000))
+        codes = np.stack([rng.integers(0, c, size=N) for c in card]).astype(np.uint8)
+        d = engine.Data(codes, card)
+        ess = float(rng.choice([0.5, 1.0, 4.0]))
+        for k in range(1, min(n, 5) + 1):
+            for kind, okind, e in ((engine.BDEU, oracle.BDEU, ess), (engine.BIC, oracle.BIC, 1.0)):
+                want = oracle.score_all(codes, card, k, okind, e, nthreads=2)
+                have = d.score_all(k, kind, e)
+                # BIC terms are N ln N sized and cancel: compare on the scale of the terms
+                scale = np.maximum(np.abs(want), N * np.log(max(N, 2)))
+                assert float(np.max(np.abs(have - want) / scale)) <= REL, (case, card, N, k, kind)
+        mp = int(rng.integers(0, n))
+        parents, total = d.exhaustive_search(min(mp, 4))
+        want_parents, want_total = oracle.exhaustive_search(codes, card, min(mp, 4))
+        assert abs(total - want_total) <= 1e-9 * max(abs(want_total), 1.0), (case, card, N, mp)
+        d.close()
