@@ -195,7 +195,15 @@ def main():
     dev_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # OBNSL_BENCH_FORCE_EXCHANGE=1: create the process group and run the all-gather
+    # and combine even with one rank (exercises the RCCL path on a one-GPU box)
+    exchange = world > 1 or os.environ.get("OBNSL_BENCH_FORCE_EXCHANGE") == "1"
+    if exchange:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -207,7 +215,8 @@ def main():
     mp = spec["max_parents"]
     kind = engine.BDEU if spec["score"] == "bdeu" else engine.BIC
 
-    hot = HotPath(codes, card, mp, kind=kind, ess=1.0, rank=rank, world=world, device_index=dev_index)
+    hot = HotPath(codes, card, mp, kind=kind, ess=1.0, rank=rank, world=world, device_index=dev_index,
+                  exchange=exchange)
     data = hot.data
     tables = hot.tables
     n_scores = hot.scores_per_pass
@@ -215,7 +224,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if exchange:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -228,7 +237,7 @@ def main():
         best = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if exchange:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -309,7 +318,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     hot.close()
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 

@@ -14,7 +14,9 @@ from . import engine
 
 class HotPath:
     def __init__(self, codes, card, max_parents, kind=engine.BDEU, ess=1.0, rank=0, world=1,
-                 device_index=0):
+                 device_index=0, exchange=None):
+        """exchange: run the all-gather + combine even in a world of one rank
+        (default: only when world > 1)."""
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
@@ -31,8 +33,9 @@ class HotPath:
         self.ptrs = [t.data_ptr() for t in self.tables]
         self.scores_per_pass = sum(self.data.num_subsets(k) * k for k in range(1, max_parents + 2))
         self.best = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
+        self.exchange = world > 1 if exchange is None else bool(exchange)
         self.gathered = (torch.empty((world, self.n, 3), dtype=torch.float64, device=self.dev)
-                         if world > 1 else None)
+                         if self.exchange else None)
         self.combined = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
 
     def step(self):
@@ -48,7 +51,7 @@ class HotPath:
             d.score_all_device(k, self.ptrs[k - 1], kind=self.kind, ess=self.ess,
                                shard=self.rank, num_shards=self.world)
         d.best_parents_device(self.ptrs, self.mp, self.best.data_ptr())
-        if self.world == 1:
+        if not self.exchange:
             return self.best
         import torch.distributed as dist
         if dist.get_backend() == "nccl":

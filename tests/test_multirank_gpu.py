@@ -57,3 +57,22 @@ def test_two_ranks_one_gpu():
     for k in range(1, 5):
         assert res[0][2][k - 1] + res[1][2][k - 1] == engine.binomial(n, k) * k
         assert min(res[0][2][k - 1], res[1][2][k - 1]) >= 0
+
+
+def test_bench_exchange_path_over_rccl_with_one_rank():
+    """bench.py with the process group, the all-gather (backend nccl = RCCL) and
+    the combine kernel switched on in a world of one rank: the code path the
+    multi-GPU runs take, as far as one GPU can exercise it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OBNSL_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "asia8_1e5_bdeu_mp2",
+                          "--steps", "3", "--warmup", "1", "--only-hot-path"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["scores_per_step"] == 232
