@@ -15,5 +15,7 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out
   python3 bench.py --steps 3 --warmup 1 --only-hot-path > gpurun_out/${tag}_write.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/${tag}_sq -- \
   python3 bench.py --steps 3 --warmup 1 --only-hot-path > gpurun_out/${tag}_sq.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_grbm -- \
+  python3 bench.py --steps 3 --warmup 1 --only-hot-path > gpurun_out/${tag}_grbm.log 2>&1
 grep '^{' gpurun_out/${tag}_trace.log > gpurun_out/${tag}_bench_under_trace.json
 echo profiled

@@ -51,6 +51,24 @@ if sq_hits:
             sq[c] = per_launch(sq_csv, c)[0]
         except ZeroDivisionError:
             pass
+clock = None
+grbm_hits = glob.glob(f"gpurun_out/{tag}_grbm/*/*counter_collection.csv")
+if grbm_hits:
+    grbm_csv = one(f"gpurun_out/{tag}_grbm/*/*counter_collection.csv")
+    shutil.copy(grbm_csv, f"profiles/{name}_pmc_grbm.csv")
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; the launch duration comes from the same rows
+    cyc, dur = [], []
+    seen = set()
+    for r in csv.DictReader(open(grbm_csv)):
+        if dominant in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            cyc.append(float(r["Counter_Value"]))
+            if "Start_Timestamp" in r and r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"])
+                dur.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    if cyc and dur and len(seen):
+        clock = {"grbm_gui_active_per_launch": sum(cyc) / len(seen),
+                 "launch_ns_under_counters": sum(dur) / len(dur),
+                 "effective_clock_ghz": (sum(cyc) / len(seen)) / 8.0 / (sum(dur) / len(dur))}
 summary = {
     "workload": workload,
     "kernel": dominant,
@@ -59,6 +77,7 @@ summary = {
     "write_bytes_per_launch": w_kib * 1024,
     "traffic_bytes_per_launch": f_kib * 1024 * 2 + w_kib * 1024,
     "instructions_per_launch": sq,
+    "clock": clock,
     "note": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/{name}_pmc_*_size.csv); "
             "counters are in KiB; FETCH_SIZE doubled (gfx950 reports half the bytes of 16-B-per-lane coalesced loads)",
 }
