@@ -28,6 +28,8 @@ WORKLOADS = {
     "hepar70_1e7_bdeu_mp3": dict(gen="hepar2", N=10_000_000, max_parents=3, score="bdeu"),
     "uniform128x4_1e7_bdeu_mp3": dict(gen="uniform128", N=10_000_000, max_parents=3, score="bdeu"),
     "asia8_1e5_bdeu_mp2": dict(gen="asia", N=100_000, max_parents=2, score="bdeu"),
+    # the 128-variable shape at a tenth of the rows (development probe of the large-tile kernel)
+    "uniform128x4_1e6_bdeu_mp3": dict(gen="uniform128", N=1_000_000, max_parents=3, score="bdeu"),
     # development probes for the path-selection threshold
     "uniform20x6_1e6_bdeu_mp3": dict(gen="uniform20x6", N=1_000_000, max_parents=3, score="bdeu"),
     "uniform20x5_1e6_bdeu_mp3": dict(gen="uniform20x5", N=1_000_000, max_parents=3, score="bdeu"),

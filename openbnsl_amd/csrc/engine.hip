@@ -183,7 +183,7 @@ __device__ __forceinline__ void tile_mac(const uint32_t* __restrict__ sA,
 // (i, j < TT), which makes every ds_read_b128 of the compute phase
 // bank-conflict free with the 36-word slab stride.
 template <int KR, int KC, int TT>
-__global__ __launch_bounds__(256) void bitgemm_kernel(
+__global__ __launch_bounds__(256, TT == 8 ? 2 : 1) void bitgemm_kernel(
     const uint32_t* __restrict__ planes, uint32_t wp, const RowDesc* __restrict__ rows,
     uint32_t nrows, const ColDesc* __restrict__ cols, uint32_t ncols_total,
     const uint2* __restrict__ items, uint32_t nitems, uint32_t* __restrict__ counts,
@@ -1235,7 +1235,10 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
   if (nshards > 1 && !rsub.empty()) {
     std::vector<uint64_t> row0(rsub.size() + 1, 0);
     for (size_t g = 0; g < rsub.size(); ++g) row0[g + 1] = row0[g] + Ms[g];
-    const uint64_t edge = (total_cost / nshards) / (128 * 128) < 2048 ? 64 : 128;
+    static const uint64_t edge = [] {
+      const char* e = std::getenv("OBNSL_TILE");
+      return e && std::atoi(e) == 128 ? 128u : 64u;
+    }();
     auto range_cost = [&](size_t lo, size_t hi) {
       uint64_t c = 0;
       size_t g = lo;
@@ -1341,9 +1344,12 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
       ++g;
     }
     // tiles: (row tile i, column tile j) for j below the tile's column limit.
-    // 128 x 128 tiles when there are enough of them to fill the chip without
-    // splitting the contraction finely, 64 x 64 otherwise (better fill of the
-    // staircase and of thin problems, 4x fewer counters flushed per workgroup).
+    // 64 x 64 tiles (16 counters per thread, 122 registers, 4 waves per SIMD).
+    // The 128 x 128 instance (64 counters per thread) needs more than 256
+    // registers: one wave per SIMD issues a vector instruction every 4 cycles
+    // instead of every 2, and capped to 256 it spills; measured 25 % and 13 %
+    // slower than 64 x 64 on 128 four-state variables, so it is kept only behind
+    // OBNSL_TILE=128 for experiments.
     auto make_tiles = [&](uint32_t tb, std::vector<std::pair<uint32_t, uint2>>& out) {
       out.clear();
       const uint32_t ntr = (uint32_t)((rows.size() + tb - 1) / tb);
@@ -1359,12 +1365,8 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
       const char* e = std::getenv("OBNSL_TILE");
       return e ? std::atoi(e) : 0;
     }();
-    make_tiles(128, tiles);
-    plan->tile = 128;
-    if (force_tile == 64 || (force_tile == 0 && tiles.size() < 2048)) {
-      make_tiles(64, tiles);
-      plan->tile = 64;
-    }
+    plan->tile = force_tile == 128 ? 128 : 64;
+    make_tiles(plan->tile, tiles);
     std::stable_sort(tiles.begin(), tiles.end(),
                      [](const std::pair<uint32_t, uint2>& a, const std::pair<uint32_t, uint2>& b) {
                        return a.first > b.first;
