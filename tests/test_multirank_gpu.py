@@ -76,3 +76,18 @@ def test_bench_exchange_path_over_rccl_with_one_rank():
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["scores_per_step"] == 232
+
+
+def test_large_tile_instances_still_count_exactly():
+    """The 128 x 128 tile instances of the counting kernel are not the default;
+    OBNSL_TILE=128 selects them (read once per process, hence the child process).
+    The smoke check compares scores of subset sizes 1..4 and one table with the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OBNSL_TILE="128")
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root,
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "smoke ok" in out.stdout
