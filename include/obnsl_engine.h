@@ -121,6 +121,26 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
  * reuse these counts.  Calling it is optional; results are the same without. */
 obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_t num_shards);
 
+/* Multi-GPU form of obnsl_precount.  The scorer of a size-k table reads the
+ * count tables of all smaller sizes, so obnsl_precount counts those whole on
+ * every rank.  This call shards the second-largest size as well: the rank
+ * counts only its slice of that table (the rest is zero) and reports
+ * *sum_size_out = that subset size and *sum_cells_out = the table's number of
+ * uint32 counters; the caller then sums the table over the ranks --
+ * obnsl_counts_export into a device buffer, all-reduce(sum) over the ranks
+ * (RCCL), obnsl_counts_import -- before the obnsl_score_all calls, which refuse
+ * to run on an unsummed table.  *sum_size_out = 0: nothing to sum (one shard,
+ * a small problem, or a size served by the per-row histogram path).
+ * No counterpart in the reference (single process). */
+obnsl_status obnsl_precount_sharded(obnsl_data* d, uint32_t kmax, uint32_t shard,
+                                    uint32_t num_shards, uint32_t* sum_size_out,
+                                    uint64_t* sum_cells_out);
+/* Copy the whole count table of subset size k (as counted for the current row
+ * bitmaps) to / from a device buffer of that many uint32; asynchronous on the
+ * data set's stream.  Import marks the table as summed. */
+obnsl_status obnsl_counts_export(obnsl_data* d, uint32_t k, uint32_t* d_dst);
+obnsl_status obnsl_counts_import(obnsl_data* d, uint32_t k, const uint32_t* d_src);
+
 /* Number of size-k subsets, C(num_vars, k), and of scores, k * C(num_vars, k). */
 obnsl_status obnsl_num_subsets(const obnsl_data* d, uint32_t k, uint64_t* num_subsets);
 

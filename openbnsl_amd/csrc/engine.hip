@@ -1055,6 +1055,8 @@ struct Plan {
   DevBuf<uint64_t> rowoff;      // by colex rank of the kr-subset
   uint64_t counted_epoch = 0;   // data epoch the counters in `red` belong to
   int pending_lane = -1;        // side lane still producing `red` (-1: none, or already joined)
+  uint64_t slice_off = 0;       // sharded plan: where its counters sit inside the whole plan's `red`
+  bool awaits_sum = false;      // whole plan: `red` holds one rank's slice, the sum over ranks is pending
   uint64_t total_items = 0;
   // per-table functional G[colex rank] of this plan's tables (see score_reduced_kernel)
   DevBuf<double> G;
@@ -1291,6 +1293,7 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     g_hi = best_cuts[shard + 1];
   }
 
+  plan->slice_off = rsub.empty() ? 0 : cum[std::min(g_lo, rsub.size())];
   std::vector<uint64_t> rowoff;
   if (reduced) rowoff.assign(binom_host(n, kr), 0);
   const uint64_t cell_cap = reduced ? (1ull << 33) : BATCH_CELL_CAP;
@@ -1494,6 +1497,12 @@ obnsl_status join_side(obnsl_data* d) {
 
 // Reduced mode: make plan->red hold the counts of the current planes.
 obnsl_status ensure_counts(obnsl_data* d, Plan* plan) {
+  if (plan->counted_epoch == d->epoch && plan->awaits_sum)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT,
+                "the count table of subset size " + std::to_string(plan->k) +
+                    " holds one rank's slice: sum it over the ranks (obnsl_counts_export / "
+                    "obnsl_counts_import) before scoring");
+  plan->awaits_sum = false;
   if (plan->counted_epoch == d->epoch) {
     if (plan->pending_lane >= 0) return join_lane(d, plan->pending_lane);
     return OBNSL_OK;
@@ -2009,7 +2018,14 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
   return OBNSL_OK;
 }
 
-obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_t num_shards) {
+}  // extern "C"
+
+namespace {
+
+obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_t num_shards,
+                           bool shard_lower, uint32_t* sum_size_out, uint64_t* sum_cells_out) {
+  if (sum_size_out) *sum_size_out = 0;
+  if (sum_cells_out) *sum_cells_out = 0;
   if (!d) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
   if (kmax == 0 || kmax > (uint32_t)KMAX || kmax > d->n)
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "subset size must be in [1, min(num_vars, OBNSL_MAX_SUBSET)]");
@@ -2072,8 +2088,29 @@ obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32
   if (kmax >= 2) {
     Plan* full = nullptr;
     st = build_plan(d, kmax - 1, 0, 1, true, &full);
-    if (st == OBNSL_OK) st = ensure_counts(d, full);
     if (st != OBNSL_OK) return st;
+    if (shard_lower && top_is_requested && num_shards > 1 &&
+        full->total_items >= 2ull * num_shards && full->counted_epoch != d->epoch) {
+      // this rank's slice only, written at its place in the whole table; the
+      // rest stays zero and the caller sums the tables of all ranks
+      Plan* part = nullptr;
+      st = build_plan(d, kmax - 1, shard, num_shards, true, &part);
+      if (st != OBNSL_OK) return st;
+      const Batch* wb = full->batches[0].get();
+      const Batch* pb = part->batches[0].get();
+      if (part->slice_off + pb->ncells > wb->ncells)
+        return fail(OBNSL_ERR_RUNTIME, "internal: slice outside the count table");
+      HIP_TRY(hipMemsetAsync(full->red.p, 0, wb->ncells * sizeof(uint32_t), d->stream));
+      st = launch_count(d, part, pb, full->red.p + part->slice_off);
+      if (st != OBNSL_OK) return st;
+      full->counted_epoch = d->epoch;
+      full->awaits_sum = true;
+      if (sum_size_out) *sum_size_out = kmax - 1;
+      if (sum_cells_out) *sum_cells_out = wb->ncells;
+    } else {
+      st = ensure_counts(d, full);
+      if (st != OBNSL_OK) return st;
+    }
   }
   bool lane1_used = false;
   for (uint32_t j = kmax >= 2 ? kmax - 2 : 0; j >= 1; --j) {
@@ -2092,6 +2129,64 @@ obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32
   }
   if (lane1_used) HIP_TRY(hipEventRecord(d->side_join[1], d->side[1]));
   return st;
+}
+
+// The whole reduced count table of subset size k, for the export / import pair.
+obnsl_status whole_table(obnsl_data* d, uint32_t k, Plan** out) {
+  if (!d) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (k == 0 || k > (uint32_t)KMAX || k > d->n)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "subset size must be in [1, min(num_vars, OBNSL_MAX_SUBSET)]");
+  obnsl_status st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  auto it = d->plans.find(std::make_tuple(k, 0u, 1u, true));
+  if (it == d->plans.end() || it->second->counted_epoch != d->epoch)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "no count table of this subset size for the current row bitmaps");
+  *out = it->second.get();
+  return OBNSL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_t num_shards) {
+  return precount_impl(d, kmax, shard, num_shards, false, nullptr, nullptr);
+}
+
+obnsl_status obnsl_precount_sharded(obnsl_data* d, uint32_t kmax, uint32_t shard,
+                                    uint32_t num_shards, uint32_t* sum_size_out,
+                                    uint64_t* sum_cells_out) {
+  if (!sum_size_out || !sum_cells_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  return precount_impl(d, kmax, shard, num_shards, true, sum_size_out, sum_cells_out);
+}
+
+obnsl_status obnsl_counts_export(obnsl_data* d, uint32_t k, uint32_t* d_dst) {
+  Plan* p = nullptr;
+  obnsl_status st = whole_table(d, k, &p);
+  if (st != OBNSL_OK) return st;
+  if (!d_dst) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (p->pending_lane >= 0) {
+    st = join_lane(d, p->pending_lane);
+    if (st != OBNSL_OK) return st;
+  }
+  HIP_TRY(hipMemcpyAsync(d_dst, p->red.p, p->batches[0]->ncells * sizeof(uint32_t),
+                         hipMemcpyDeviceToDevice, d->stream));
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_counts_import(obnsl_data* d, uint32_t k, const uint32_t* d_src) {
+  Plan* p = nullptr;
+  obnsl_status st = whole_table(d, k, &p);
+  if (st != OBNSL_OK) return st;
+  if (!d_src) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (p->pending_lane >= 0) {
+    st = join_lane(d, p->pending_lane);
+    if (st != OBNSL_OK) return st;
+  }
+  HIP_TRY(hipMemcpyAsync(p->red.p, d_src, p->batches[0]->ncells * sizeof(uint32_t),
+                         hipMemcpyDeviceToDevice, d->stream));
+  p->awaits_sum = false;
+  return OBNSL_OK;
 }
 
 obnsl_status obnsl_score_subsets(obnsl_data* d, obnsl_score_kind kind, double ess,

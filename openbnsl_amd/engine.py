@@ -42,6 +42,10 @@ SIGNATURES = {
     "obnsl_score_all": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
                                        ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_int]),
     "obnsl_precount": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
+    "obnsl_precount_sharded": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                              _u32p, _u64p]),
+    "obnsl_counts_export": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
+    "obnsl_counts_import": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
     "obnsl_num_subsets": (ctypes.c_int, [_vp, ctypes.c_uint32, _u64p]),
     "obnsl_score_subsets": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, _u32p,
                                            ctypes.c_uint32, ctypes.c_uint64, _f64p]),
@@ -205,6 +209,21 @@ class Data:
 
     def precount(self, kmax, shard=0, num_shards=1):
         _check(lib.obnsl_precount(self._h, kmax, shard, num_shards))
+
+    def precount_sharded(self, kmax, shard, num_shards):
+        """(subset size whose count table must be summed over the ranks, its number of
+        uint32 counters); (0, 0) when there is nothing to sum."""
+        size = ctypes.c_uint32(0)
+        cells = ctypes.c_uint64(0)
+        _check(lib.obnsl_precount_sharded(self._h, kmax, shard, num_shards, ctypes.byref(size),
+                                          ctypes.byref(cells)))
+        return size.value, cells.value
+
+    def counts_export(self, k, dst_ptr):
+        _check(lib.obnsl_counts_export(self._h, k, dst_ptr))
+
+    def counts_import(self, k, src_ptr):
+        _check(lib.obnsl_counts_import(self._h, k, src_ptr))
 
     def num_subsets(self, k):
         return binomial(self.n, k)

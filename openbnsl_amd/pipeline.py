@@ -1,8 +1,10 @@
 """The whole hot path as one object: what one rank does per pass.
 
-    pack -> for k = 1..max_parents+1: count + score this rank's shard of the
-    size-k subsets -> per-node best parent sets of the shard -> (world > 1)
-    all-gather of those records and the deterministic combine.
+    pack -> count (largest size: this rank's shard; second largest: this rank's
+    slice, then all-reduce of that count table; smaller sizes whole) -> for
+    k = 1..max_parents+1 score this rank's shard of the size-k subsets ->
+    per-node best parent sets of the shard -> (world > 1) all-gather of those
+    records and the deterministic combine.
 
 Used by bench.py (timed) and by the multi-rank tests.  PyTorch provides the
 device score tables, the stream and torch.distributed; every kernel launched is
@@ -37,6 +39,7 @@ class HotPath:
         self.gathered = (torch.empty((world, self.n, 3), dtype=torch.float64, device=self.dev)
                          if self.exchange else None)
         self.combined = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
+        self.count_buf = None
 
     def step(self):
         """One pass, queued asynchronously on the current stream (no host
@@ -46,7 +49,14 @@ class HotPath:
         torch = self.torch
         d = self.data
         d.pack()
-        d.precount(self.mp + 1, self.rank, self.world)
+        if self.world > 1 and self.exchange:
+            # the second-largest size is counted in slices too; its table is summed
+            # over the ranks before anything is scored from it
+            size, cells = d.precount_sharded(self.mp + 1, self.rank, self.world)
+            if size:
+                self._sum_counts(size, cells)
+        else:
+            d.precount(self.mp + 1, self.rank, self.world)
         for k in range(1, self.mp + 2):
             d.score_all_device(k, self.ptrs[k - 1], kind=self.kind, ess=self.ess,
                                shard=self.rank, num_shards=self.world)
@@ -64,6 +74,21 @@ class HotPath:
             self.gathered.copy_(out)
         d.combine_best_device(self.gathered.data_ptr(), self.world, self.combined.data_ptr())
         return self.combined
+
+    def _sum_counts(self, size, cells):
+        torch = self.torch
+        import torch.distributed as dist
+        if self.count_buf is None or self.count_buf.numel() < cells:
+            self.count_buf = torch.empty(cells, dtype=torch.int32, device=self.dev)
+        buf = self.count_buf[:cells]
+        self.data.counts_export(size, buf.data_ptr())
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(buf)        # disjoint slices, zero elsewhere: the sum is the whole table
+        else:
+            host = buf.cpu()            # gloo: host tensors only
+            dist.all_reduce(host)
+            buf.copy_(host)
+        self.data.counts_import(size, buf.data_ptr())
 
     @staticmethod
     def to_host(best):

@@ -364,3 +364,58 @@ def test_randomised_sweep_against_the_oracle(engine):
         want_parents, want_total = oracle.exhaustive_search(codes, card, min(mp, 4))
         assert abs(total - want_total) <= 1e-9 * max(abs(want_total), 1.0), (case, card, N, mp)
         d.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_second_size_sums_to_the_whole_table(engine, world):
+    """obnsl_precount_sharded: each "rank" (its own data set object here) counts
+    a slice of the second-largest size; the slices are disjoint, their sum is the
+    whole table, scoring refuses an unsummed table, and after the import every
+    rank's scores equal the unsharded ones."""
+    torch = pytest.importorskip("torch")
+    import oracle
+    from openbnsl_amd import synth
+    cards = [2, 3, 4, 2, 3, 4, 3, 2, 4, 3, 2, 3, 4, 2, 3, 3, 2, 4, 2, 3, 4, 2, 3, 2, 4, 3, 2, 2, 3, 4]
+    codes, card, _, _ = synth.random_bn(cards, 4_000, seed=21)
+    n, kmax = len(cards), 4
+    ranks = [engine.Data(codes, card) for _ in range(world)]
+    parts = []
+    for r, d in enumerate(ranks):
+        size, cells = d.precount_sharded(kmax, r, world)
+        assert size == kmax - 1 and cells > 0
+        buf = torch.empty(cells, dtype=torch.int32, device="cuda")
+        d.counts_export(size, buf.data_ptr())
+        torch.cuda.synchronize()
+        parts.append(buf)
+        out = torch.empty(d.num_subsets(2) * 2, dtype=torch.float64, device="cuda")
+        d.score_all_device(1, torch.empty(n, dtype=torch.float64, device="cuda").data_ptr(),
+                           shard=r, num_shards=world)          # sizes below the slice are whole
+        with pytest.raises(ValueError, match="one rank's slice"):
+            d.score_all_device(kmax, torch.empty(d.num_subsets(kmax) * kmax, dtype=torch.float64,
+                                                 device="cuda").data_ptr(), shard=r, num_shards=world)
+    stack = torch.stack(parts)
+    assert int(((stack != 0).sum(dim=0) > 1).sum()) == 0        # disjoint slices
+    total = stack.sum(dim=0, dtype=torch.int32)
+    whole = engine.Data(codes, card)
+    whole.precount(kmax - 1)
+    ref = torch.empty_like(total)
+    whole.counts_export(kmax - 1, ref.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(total, ref)
+    want = oracle.score_all(codes, card, kmax, nthreads=4)
+    T = ranks[0].num_subsets(kmax)
+    outs = []
+    for r, d in enumerate(ranks):
+        d.counts_import(kmax - 1, total.data_ptr())
+        buf = torch.full((T * kmax,), float("-inf"), dtype=torch.float64, device="cuda")
+        for k in range(1, kmax):
+            d.score_all_device(k, torch.empty(d.num_subsets(k) * k, dtype=torch.float64,
+                                              device="cuda").data_ptr(), shard=r, num_shards=world)
+        d.score_all_device(kmax, buf.data_ptr(), shard=r, num_shards=world)
+        torch.cuda.synchronize()
+        outs.append(buf)
+    st = torch.stack(outs)
+    assert int((st > float("-inf")).sum(dim=0).min()) == 1 and int((st > float("-inf")).sum(dim=0).max()) == 1
+    assert rel_err(st.max(dim=0).values.cpu().numpy().reshape(T, kmax), want) <= REL
+    for d in ranks + [whole]:
+        d.close()

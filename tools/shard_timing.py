@@ -15,6 +15,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="alarm37_1e6_bdeu_mp3")
 ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--shard-lower", action="store_true",
+                help="count the second-largest size in slices too (the sum over ranks is replaced by a "
+                     "copy out and back in: same device work, no collective)")
 args = ap.parse_args()
 spec = bench.WORKLOADS[args.workload]
 codes, card, names = bench.make_data(spec)
@@ -33,9 +36,17 @@ for world in [int(x) for x in args.worlds.split(",")]:
         for t in tabs:
             t.fill_(float("-inf"))
 
+        cbuf = torch.empty(1 << 24, dtype=torch.int32, device="cuda")
+
         def step():
             d.pack()
-            d.precount(mp + 1, rank, world)
+            if args.shard_lower and world > 1:
+                size, cells = d.precount_sharded(mp + 1, rank, world)
+                if size:
+                    d.counts_export(size, cbuf.data_ptr())
+                    d.counts_import(size, cbuf.data_ptr())
+            else:
+                d.precount(mp + 1, rank, world)
             for k in range(1, mp + 2):
                 d.score_all_device(k, ptrs[k - 1], kind=kind, ess=1.0, shard=rank, num_shards=world)
             d.best_parents_device(ptrs, mp, best.data_ptr())
