@@ -50,3 +50,17 @@ def allgather_best(score, size, rank, device=None):
     out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
     dist.all_gather_into_tensor(out.view(-1), mine.reshape(-1).contiguous())
     return combine_best(out.cpu().numpy())
+
+
+def sum_count_table(table):
+    """All-reduce(sum) of a count table of which every rank holds a disjoint
+    slice (zero elsewhere): int32 torch tensor, summed in place.  Device tensor
+    over nccl; over gloo the sum runs on a host copy."""
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl" or not table.is_cuda:
+        dist.all_reduce(table)
+        return table
+    host = table.cpu()
+    dist.all_reduce(host)
+    table.copy_(host)
+    return table

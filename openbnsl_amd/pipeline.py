@@ -11,6 +11,7 @@ device score tables, the stream and torch.distributed; every kernel launched is
 the engine's (include/obnsl_engine.h)."""
 import numpy as np
 
+from . import distributed as obd
 from . import engine
 
 
@@ -77,17 +78,11 @@ class HotPath:
 
     def _sum_counts(self, size, cells):
         torch = self.torch
-        import torch.distributed as dist
         if self.count_buf is None or self.count_buf.numel() < cells:
             self.count_buf = torch.empty(cells, dtype=torch.int32, device=self.dev)
         buf = self.count_buf[:cells]
         self.data.counts_export(size, buf.data_ptr())
-        if dist.get_backend() == "nccl":
-            dist.all_reduce(buf)        # disjoint slices, zero elsewhere: the sum is the whole table
-        else:
-            host = buf.cpu()            # gloo: host tensors only
-            dist.all_reduce(host)
-            buf.copy_(host)
+        obd.sum_count_table(buf)        # disjoint slices, zero elsewhere: the sum is the whole table
         self.data.counts_import(size, buf.data_ptr())
 
     @staticmethod
