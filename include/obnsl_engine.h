@@ -135,9 +135,11 @@ obnsl_status obnsl_precount(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32
 obnsl_status obnsl_precount_sharded(obnsl_data* d, uint32_t kmax, uint32_t shard,
                                     uint32_t num_shards, uint32_t* sum_size_out,
                                     uint64_t* sum_cells_out);
-/* Copy the whole count table of subset size k (as counted for the current row
- * bitmaps) to / from a device buffer of that many uint32; asynchronous on the
- * data set's stream.  Import marks the table as summed. */
+/* The whole count table of subset size k, as counted for the current row
+ * bitmaps: its number of uint32 counters, and copies to / from a device buffer
+ * of that size, asynchronous on the data set's stream.  Import marks the table
+ * as summed. */
+obnsl_status obnsl_counts_cells(obnsl_data* d, uint32_t k, uint64_t* cells_out);
 obnsl_status obnsl_counts_export(obnsl_data* d, uint32_t k, uint32_t* d_dst);
 obnsl_status obnsl_counts_import(obnsl_data* d, uint32_t k, const uint32_t* d_src);
 

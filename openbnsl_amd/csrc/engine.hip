@@ -2160,6 +2160,15 @@ obnsl_status obnsl_precount_sharded(obnsl_data* d, uint32_t kmax, uint32_t shard
   return precount_impl(d, kmax, shard, num_shards, true, sum_size_out, sum_cells_out);
 }
 
+obnsl_status obnsl_counts_cells(obnsl_data* d, uint32_t k, uint64_t* cells_out) {
+  Plan* p = nullptr;
+  obnsl_status st = whole_table(d, k, &p);
+  if (st != OBNSL_OK) return st;
+  if (!cells_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  *cells_out = p->batches[0]->ncells;
+  return OBNSL_OK;
+}
+
 obnsl_status obnsl_counts_export(obnsl_data* d, uint32_t k, uint32_t* d_dst) {
   Plan* p = nullptr;
   obnsl_status st = whole_table(d, k, &p);

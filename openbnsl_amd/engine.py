@@ -44,6 +44,7 @@ SIGNATURES = {
     "obnsl_precount": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "obnsl_precount_sharded": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                               _u32p, _u64p]),
+    "obnsl_counts_cells": (ctypes.c_int, [_vp, ctypes.c_uint32, _u64p]),
     "obnsl_counts_export": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
     "obnsl_counts_import": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
     "obnsl_num_subsets": (ctypes.c_int, [_vp, ctypes.c_uint32, _u64p]),
@@ -218,6 +219,11 @@ class Data:
         _check(lib.obnsl_precount_sharded(self._h, kmax, shard, num_shards, ctypes.byref(size),
                                           ctypes.byref(cells)))
         return size.value, cells.value
+
+    def counts_cells(self, k):
+        cells = ctypes.c_uint64(0)
+        _check(lib.obnsl_counts_cells(self._h, k, ctypes.byref(cells)))
+        return cells.value
 
     def counts_export(self, k, dst_ptr):
         _check(lib.obnsl_counts_export(self._h, k, dst_ptr))

@@ -58,6 +58,10 @@ class HotPath:
                 self._sum_counts(size, cells)
         else:
             d.precount(self.mp + 1, self.rank, self.world)
+            if self.exchange and self.mp >= 1:
+                # a world of one rank with the exchange forced on: the same export ->
+                # all-reduce -> import round trip (the sum of one table is itself)
+                self._sum_counts(self.mp, d.counts_cells(self.mp))
         for k in range(1, self.mp + 2):
             d.score_all_device(k, self.ptrs[k - 1], kind=self.kind, ess=self.ess,
                                shard=self.rank, num_shards=self.world)
