@@ -98,6 +98,15 @@ struct TableDesc {      // explicit table for the list-form / single-table score
   uint32_t cards[KMAX];
 };
 
+// Count tables that the pack kernel clears on the side (the split-contraction
+// launches add into them with atomics and would otherwise each need a fill first).
+constexpr int ZERO_MAX = 8;
+struct ZeroList {
+  uint32_t* p[ZERO_MAX];
+  uint64_t n[ZERO_MAX];
+  int count;
+};
+
 // ------------------------------------------------------------------ pack kernel
 // One thread builds one 32-row word of every state plane of one variable.
 // Bit b of word w is row 32*w + b.  Rows >= N contribute zero bits.
@@ -105,7 +114,13 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(
     const uint8_t* __restrict__ codes, uint64_t N, uint64_t stride, uint32_t n,
     const uint32_t* __restrict__ card, const uint32_t* __restrict__ plane_base,
     uint32_t* __restrict__ planes, uint32_t wp, uint32_t ones_plane,
-    uint32_t* __restrict__ bad_code) {
+    uint32_t* __restrict__ bad_code, ZeroList zl) {
+  if (zl.count) {
+    const uint64_t nthreads = (uint64_t)gridDim.x * gridDim.y * 256;
+    const uint64_t me = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    for (int b = 0; b < zl.count; ++b)
+      for (uint64_t i = me; i < zl.n[b]; i += nthreads) zl.p[b][i] = 0;
+  }
   const uint32_t w = blockIdx.x * 256 + threadIdx.x;
   if (w >= wp) return;
   const uint32_t v = blockIdx.y;
@@ -1055,6 +1070,8 @@ struct Plan {
   DevBuf<uint64_t> rowoff;      // by colex rank of the kr-subset
   uint64_t counted_epoch = 0;   // data epoch the counters in `red` belong to
   int pending_lane = -1;        // side lane still producing `red` (-1: none, or already joined)
+  uint64_t zeroed_epoch = 0;    // data epoch at whose pack `red` was cleared
+  bool wants_zero = false;      // the last count into `red` added with atomics (or filled a slice of it)
   uint64_t slice_off = 0;       // sharded plan: where its counters sit inside the whole plan's `red`
   bool awaits_sum = false;      // whole plan: `red` holds one rank's slice, the sum over ranks is pending
   uint64_t total_items = 0;
@@ -1427,7 +1444,8 @@ void launch_bitgemm(obnsl_data* d, const Plan* p, const Batch* b, uint32_t* coun
 }
 
 // One bit-GEMM launch (timed with an event pair) filling `counts` for one batch.
-obnsl_status launch_count(obnsl_data* d, const Plan* plan, const Batch* b, uint32_t* counts) {
+obnsl_status launch_count(obnsl_data* d, Plan* plan, const Batch* b, uint32_t* counts,
+                          bool prezeroed = false) {
   if (b->nitems == 0) return OBNSL_OK;
   const uint32_t steps_total = d->wp / KCW;
   // split the contraction when there are too few tiles to fill the chip
@@ -1448,7 +1466,9 @@ obnsl_status launch_count(obnsl_data* d, const Plan* plan, const Batch* b, uint3
   ksplit = (steps_total + sps - 1) / sps;
   static const int nojskip = std::getenv("OBNSL_NO_JSKIP") ? 2 : 0;
   const int atomics = (ksplit > 1 ? 1 : 0) | nojskip;
-  if (atomics & 1) HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
+  if ((atomics & 1) && !prezeroed)
+    HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
+  if (counts == plan->red.p) plan->wants_zero = (atomics & 1) != 0;
   if (d->ev_used >= 4096) {  // bound the pool: fold what has been recorded so far
     obnsl_status st = resolve_events(d);
     if (st != OBNSL_OK) return st;
@@ -1507,7 +1527,8 @@ obnsl_status ensure_counts(obnsl_data* d, Plan* plan) {
     if (plan->pending_lane >= 0) return join_lane(d, plan->pending_lane);
     return OBNSL_OK;
   }
-  obnsl_status st = launch_count(d, plan, plan->batches[0].get(), plan->red.p);
+  obnsl_status st = launch_count(d, plan, plan->batches[0].get(), plan->red.p,
+                                 plan->zeroed_epoch == d->epoch);
   if (st != OBNSL_OK) return st;
   plan->counted_epoch = d->epoch;
   return OBNSL_OK;
@@ -1687,12 +1708,28 @@ obnsl_status set_device(int device) {
 obnsl_status run_pack(obnsl_data* d, uint32_t* bad_code = nullptr) {
   obnsl_status js = join_side(d);  // a count launch may still be reading the planes
   if (js != OBNSL_OK) return js;
+  // count tables that were filled with atomics for the planes being replaced will
+  // be filled the same way for the new ones: clear them here instead of one fill each
+  ZeroList zl;
+  std::memset(&zl, 0, sizeof(zl));
+  Plan* cleared[ZERO_MAX];
+  for (auto& kv : d->plans) {
+    Plan* p = kv.second.get();
+    if (zl.count == ZERO_MAX) break;
+    if (!p->reduced || !p->wants_zero || p->counted_epoch != d->epoch || !p->red.p) continue;
+    if (p->batches[0]->ncells > (1ull << 26)) continue;  // large tables keep their own fill
+    cleared[zl.count] = p;
+    zl.p[zl.count] = p->red.p;
+    zl.n[zl.count] = p->batches[0]->ncells;
+    ++zl.count;
+  }
   dim3 grid((d->wp + 255) / 256, d->n + 1);
   hipLaunchKernelGGL(pack_planes_kernel, grid, dim3(256), 0, d->stream, d->codes.p, d->N,
                      d->stride, d->n, d->d_card.p, d->d_plane_base.p, d->planes.p, d->wp,
-                     d->ones_plane, bad_code);
+                     d->ones_plane, bad_code, zl);
   HIP_TRY(hipGetLastError());
   d->epoch++;  // every cached count table is stale now
+  for (int i = 0; i < zl.count; ++i) cleared[i]->zeroed_epoch = d->epoch;
   return OBNSL_OK;
 }
 
@@ -2100,8 +2137,10 @@ obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_
       const Batch* pb = part->batches[0].get();
       if (part->slice_off + pb->ncells > wb->ncells)
         return fail(OBNSL_ERR_RUNTIME, "internal: slice outside the count table");
-      HIP_TRY(hipMemsetAsync(full->red.p, 0, wb->ncells * sizeof(uint32_t), d->stream));
-      st = launch_count(d, part, pb, full->red.p + part->slice_off);
+      if (full->zeroed_epoch != d->epoch)
+        HIP_TRY(hipMemsetAsync(full->red.p, 0, wb->ncells * sizeof(uint32_t), d->stream));
+      full->wants_zero = true;
+      st = launch_count(d, part, pb, full->red.p + part->slice_off, true);
       if (st != OBNSL_OK) return st;
       full->counted_epoch = d->epoch;
       full->awaits_sum = true;
