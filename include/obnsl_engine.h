@@ -140,6 +140,13 @@ obnsl_status obnsl_precount_sharded(obnsl_data* d, uint32_t kmax, uint32_t shard
  * of that size, asynchronous on the data set's stream.  Import marks the table
  * as summed. */
 obnsl_status obnsl_counts_cells(obnsl_data* d, uint32_t k, uint64_t* cells_out);
+/* For callers that can run the all-reduce on the engine's own memory: the device
+ * address of that table (stable while the data set lives; work queued on the
+ * data set's stream so far is ordered before anything the caller queues there),
+ * and the acknowledgement that it now holds the sum over the ranks. */
+obnsl_status obnsl_counts_pointer(obnsl_data* d, uint32_t k, uint32_t** d_table_out,
+                                  uint64_t* cells_out);
+obnsl_status obnsl_counts_mark_summed(obnsl_data* d, uint32_t k);
 obnsl_status obnsl_counts_export(obnsl_data* d, uint32_t k, uint32_t* d_dst);
 obnsl_status obnsl_counts_import(obnsl_data* d, uint32_t k, const uint32_t* d_src);
 

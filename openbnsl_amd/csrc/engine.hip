@@ -2208,6 +2208,29 @@ obnsl_status obnsl_counts_cells(obnsl_data* d, uint32_t k, uint64_t* cells_out) 
   return OBNSL_OK;
 }
 
+obnsl_status obnsl_counts_pointer(obnsl_data* d, uint32_t k, uint32_t** d_table_out,
+                                  uint64_t* cells_out) {
+  Plan* p = nullptr;
+  obnsl_status st = whole_table(d, k, &p);
+  if (st != OBNSL_OK) return st;
+  if (!d_table_out || !cells_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (p->pending_lane >= 0) {
+    st = join_lane(d, p->pending_lane);
+    if (st != OBNSL_OK) return st;
+  }
+  *d_table_out = p->red.p;
+  *cells_out = p->batches[0]->ncells;
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_counts_mark_summed(obnsl_data* d, uint32_t k) {
+  Plan* p = nullptr;
+  obnsl_status st = whole_table(d, k, &p);
+  if (st != OBNSL_OK) return st;
+  p->awaits_sum = false;
+  return OBNSL_OK;
+}
+
 obnsl_status obnsl_counts_export(obnsl_data* d, uint32_t k, uint32_t* d_dst) {
   Plan* p = nullptr;
   obnsl_status st = whole_table(d, k, &p);

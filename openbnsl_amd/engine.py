@@ -45,6 +45,8 @@ SIGNATURES = {
     "obnsl_precount_sharded": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                               _u32p, _u64p]),
     "obnsl_counts_cells": (ctypes.c_int, [_vp, ctypes.c_uint32, _u64p]),
+    "obnsl_counts_pointer": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.POINTER(_vp), _u64p]),
+    "obnsl_counts_mark_summed": (ctypes.c_int, [_vp, ctypes.c_uint32]),
     "obnsl_counts_export": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
     "obnsl_counts_import": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
     "obnsl_num_subsets": (ctypes.c_int, [_vp, ctypes.c_uint32, _u64p]),
@@ -224,6 +226,16 @@ class Data:
         cells = ctypes.c_uint64(0)
         _check(lib.obnsl_counts_cells(self._h, k, ctypes.byref(cells)))
         return cells.value
+
+    def counts_pointer(self, k):
+        """(device address, number of uint32 counters) of the whole size-k count table."""
+        ptr = _vp()
+        cells = ctypes.c_uint64(0)
+        _check(lib.obnsl_counts_pointer(self._h, k, ctypes.byref(ptr), ctypes.byref(cells)))
+        return ptr.value, cells.value
+
+    def counts_mark_summed(self, k):
+        _check(lib.obnsl_counts_mark_summed(self._h, k))
 
     def counts_export(self, k, dst_ptr):
         _check(lib.obnsl_counts_export(self._h, k, dst_ptr))

@@ -15,6 +15,14 @@ from . import distributed as obd
 from . import engine
 
 
+class _DeviceInts:
+    """int32 view of `n` device words at `ptr` for torch.as_tensor."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
 class HotPath:
     def __init__(self, codes, card, max_parents, kind=engine.BDEU, ess=1.0, rank=0, world=1,
                  device_index=0, exchange=None):
@@ -40,7 +48,7 @@ class HotPath:
         self.gathered = (torch.empty((world, self.n, 3), dtype=torch.float64, device=self.dev)
                          if self.exchange else None)
         self.combined = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
-        self.count_buf = None
+        self._count_views = {}
 
     def step(self):
         """One pass, queued asynchronously on the current stream (no host
@@ -81,13 +89,16 @@ class HotPath:
         return self.combined
 
     def _sum_counts(self, size, cells):
-        torch = self.torch
-        if self.count_buf is None or self.count_buf.numel() < cells:
-            self.count_buf = torch.empty(cells, dtype=torch.int32, device=self.dev)
-        buf = self.count_buf[:cells]
-        self.data.counts_export(size, buf.data_ptr())
-        obd.sum_count_table(buf)        # disjoint slices, zero elsewhere: the sum is the whole table
-        self.data.counts_import(size, buf.data_ptr())
+        """All-reduce of the engine's own count table, in place: a tensor that
+        aliases the table's device memory (CUDA array interface)."""
+        ptr, cells = self.data.counts_pointer(size)
+        view = self._count_views.get((ptr, cells))
+        if view is None:
+            view = self.torch.as_tensor(_DeviceInts(ptr, cells), device=self.dev)
+            assert view.data_ptr() == ptr
+            self._count_views[(ptr, cells)] = view
+        obd.sum_count_table(view)       # disjoint slices, zero elsewhere: the sum is the whole table
+        self.data.counts_mark_summed(size)
 
     @staticmethod
     def to_host(best):

@@ -16,8 +16,8 @@ ap.add_argument("--workload", default="alarm37_1e6_bdeu_mp3")
 ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--shard-lower", action="store_true",
-                help="count the second-largest size in slices too (the sum over ranks is replaced by a "
-                     "copy out and back in: same device work, no collective)")
+                help="count the second-largest size in slices too (the sum over ranks is left out: "
+                     "same counting work, no collective)")
 args = ap.parse_args()
 spec = bench.WORKLOADS[args.workload]
 codes, card, names = bench.make_data(spec)
@@ -43,8 +43,8 @@ for world in [int(x) for x in args.worlds.split(",")]:
             if args.shard_lower and world > 1:
                 size, cells = d.precount_sharded(mp + 1, rank, world)
                 if size:
-                    d.counts_export(size, cbuf.data_ptr())
-                    d.counts_import(size, cbuf.data_ptr())
+                    d.counts_pointer(size)      # where the in-place all-reduce would run
+                    d.counts_mark_summed(size)
             else:
                 d.precount(mp + 1, rank, world)
             for k in range(1, mp + 2):
