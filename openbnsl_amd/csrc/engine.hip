@@ -1980,6 +1980,10 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
     ReducedViews views;
     std::memset(&views, 0, sizeof(views));
     Plan* own = nullptr;     // lists this shard's tables
+    const double N_d = (double)d->N;
+    const double g0 = kind == OBNSL_SCORE_BDEU ? std::lgamma(N_d + ess) - std::lgamma(ess)
+                                               : N_d * std::log(N_d);
+    const double* gprev = nullptr;
     for (uint32_t j = 1; j <= k; ++j) {
       Plan* full = nullptr;
       Plan* use = nullptr;
@@ -1989,6 +1993,20 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
         use = full;
       }
       if (j == k) {
+        // G of the next smaller size, over ALL its subsets (cached per data epoch).
+        // Queued before this size's counts are waited for: those may still be in
+        // flight on a side stream, and this launch does not read them.
+        if (k > 1) {
+          Plan* prev = nullptr;
+          st = build_plan(d, k - 1, 0, 1, true, &prev);
+          if (st != OBNSL_OK) return st;
+          if (!(prev->g_epoch == d->epoch && prev->g_kind == (int)kind && prev->g_ess == ess)) {
+            ReducedViews pv = views;  // sizes 1..k-1 are the full plans already; v[k] is still empty
+            st = run_functional(d, prev, pv, k - 1, max_cells, kind, ess, nullptr, 0.0, nullptr);
+            if (st != OBNSL_OK) return st;
+          }
+          gprev = prev->G.p;
+        }
         st = build_plan(d, k, shard, num_shards, true, &own);
         if (st != OBNSL_OK) return st;
         if (num_shards > 1) {
@@ -2005,23 +2023,6 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
       views.v[j].cgs = use->cgs.p;
       views.v[j].kr = use->kr;
       views.v[j].kc = use->kc;
-    }
-    // G of the next smaller size, over ALL its subsets (cached per data epoch)
-    const double N_d = (double)d->N;
-    const double g0 = kind == OBNSL_SCORE_BDEU ? std::lgamma(N_d + ess) - std::lgamma(ess)
-                                               : N_d * std::log(N_d);
-    const double* gprev = nullptr;
-    if (k > 1) {
-      Plan* prev = nullptr;
-      st = build_plan(d, k - 1, 0, 1, true, &prev);
-      if (st != OBNSL_OK) return st;
-      if (!(prev->g_epoch == d->epoch && prev->g_kind == (int)kind && prev->g_ess == ess)) {
-        ReducedViews pv = views;  // sizes 1..k-1 are the full plans already
-        std::memset(&pv.v[k], 0, sizeof(SizeView));
-        st = run_functional(d, prev, pv, k - 1, max_cells, kind, ess, nullptr, 0.0, nullptr);
-        if (st != OBNSL_OK) return st;
-      }
-      gprev = prev->G.p;
     }
     st = run_functional(d, own, views, k, max_cells, kind, ess, gprev, g0, d_scores);
     if (st != OBNSL_OK) return st;
