@@ -19,6 +19,11 @@
  *  - size-k subsets are numbered by colex rank, rank(S) = sum_j C(v_j, j) for
  *    v_1 < ... < v_k, which is the order in which the reference visits them
  *    (Gosper order, src/structure_learning/exhaustive_search.cpp:51-52,129);
+ *  - an obnsl_data handle serves one call at a time (the caller serialises calls
+ *    on one handle; different handles may be used from different threads).  The
+ *    reference holds the GIL for the whole of every call
+ *    (bindings/pybind_module.cpp: no gil_scoped_release), so it makes no promise
+ *    beyond that either;
  *  - all compute runs on the GPU; there is no CPU fallback.  Without a usable
  *    HIP device every compute call fails with OBNSL_ERR_NO_DEVICE.
  */
