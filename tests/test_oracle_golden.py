@@ -115,3 +115,47 @@ def test_bic_matches_numpy_restatement():
         want = ll - 0.5 * np.log(codes.shape[1]) * q * (shape[ci] - 1)
         have = oracle.local_score(cnt.astype(np.uint64), card[vs], ci, oracle.BIC)
         assert abs(have - want) <= 1e-9 * abs(want)
+
+
+@pytest.mark.parametrize("cards,N,mp,seed", [([2, 3, 2, 2], 400, 3, 1), ([3, 2, 4, 2, 3], 600, 2, 2),
+                                             ([2, 2, 2, 3, 2], 300, 4, 3)])
+def test_exhaustive_search_optimum_against_all_dags(cards, N, mp, seed):
+    """The search restated in oracle.c (src/structure_learning/exhaustive_search.cpp:47-148
+    cannot be compiled here) must return a highest-scoring DAG: every DAG on the
+    4 or 5 nodes with at most max_parents parents per node is enumerated (as
+    parent-set choices that admit a topological order) and scored from the
+    oracle's local scores, which are pinned to the reference bit for bit."""
+    import itertools
+    from openbnsl_amd import synth
+    codes, card, _, _ = synth.random_bn(cards, N, seed=seed)
+    n = len(cards)
+    local = {}
+    for v in range(n):
+        others = [u for u in range(n) if u != v]
+        for k in range(0, mp + 1):
+            for ps in itertools.combinations(others, k):
+                vs = sorted(ps + (v,))
+                cnt = oracle.count(codes, card, vs)
+                local[(v, ps)] = oracle.local_score(cnt, card[vs], vs.index(v))
+    best = -np.inf
+    choices = [[ps for (v, ps) in local if v == node] for node in range(n)]
+
+    def acyclic(assign):
+        left = {v: set(ps) for v, ps in enumerate(assign)}
+        while left:
+            free = [v for v, ps in left.items() if not ps]
+            if not free:
+                return False
+            for v in free:
+                del left[v]
+            for ps in left.values():
+                ps.difference_update(free)
+        return True
+
+    for assign in itertools.product(*choices):
+        if acyclic(assign):
+            best = max(best, sum(local[(v, ps)] for v, ps in enumerate(assign)))
+    parents, total = oracle.exhaustive_search(codes, card, mp)
+    assert abs(total - best) <= 1e-9 * abs(best)
+    got = sum(local[(v, tuple(ps))] for v, ps in enumerate(parents))
+    assert abs(got - best) <= 1e-9 * abs(best) and acyclic([tuple(p) for p in parents])
