@@ -355,6 +355,47 @@ __global__ __launch_bounds__(256) void count_single_kernel(
   }
 }
 
+// The same for a list of explicit subsets of one size in ONE launch: table
+// blockIdx.x of the list (cells off[t] .. off[t+1] of `counts`), blockIdx.y
+// strides over its cells, blockIdx.z over chunks of the rows.  The row chunk is
+// the slowest grid dimension: the workgroups in flight together read the same
+// words of (different) planes, a working set that stays in L2.
+__global__ __launch_bounds__(256) void count_list_kernel(
+    const uint32_t* __restrict__ planes, uint32_t wp, uint32_t k,
+    const uint32_t* __restrict__ pbase_all, const TableDesc* __restrict__ tds,
+    uint32_t* __restrict__ counts, uint32_t ones_plane) {
+  __shared__ uint32_t red[4];
+  const uint64_t t = blockIdx.x;
+  const uint32_t* __restrict__ pbase = pbase_all + t * KMAX;
+  const uint32_t* __restrict__ cards = tds[t].cards;
+  uint32_t cells = 1;
+  for (uint32_t j = 0; j < k; ++j) cells *= cards[j];
+  uint32_t* __restrict__ dst = counts + tds[t].off;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t cell = blockIdx.y; cell < cells; cell += gridDim.y) {
+    uint32_t pl[KMAX];
+    uint32_t rem = cell;
+    for (int j = (int)k - 1; j >= 0; --j) {
+      pl[j] = pbase[j] + rem % cards[j];
+      rem /= cards[j];
+    }
+    uint32_t acc = 0;
+    for (uint32_t w = blockIdx.z * 256 + threadIdx.x; w < wp; w += gridDim.z * 256) {
+      uint32_t x = planes[(size_t)ones_plane * wp + w];
+      for (uint32_t j = 0; j < k; ++j) x &= planes[(size_t)pl[j] * wp + w];
+      acc += __popc(x);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t tot = red[0] + red[1] + red[2] + red[3];
+      if (tot) atomicAdd(&dst[cell], tot);
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ scoring
 // lgamma(x) for x > 0: shift the argument up to >= 16 with the recurrence
 // lgamma(x) = lgamma(x + m) - ln(x (x+1) ... (x+m-1)), then the Stirling series
@@ -2271,7 +2312,7 @@ obnsl_status obnsl_score_subsets(obnsl_data* d, obnsl_score_kind kind, double es
   st = set_device(d->device);
   if (st != OBNSL_OK) return st;
   std::vector<TableDesc> tds(m);
-  std::vector<uint32_t> pb(m * KMAX, 0), cd(m * KMAX, 1);
+  std::vector<uint32_t> pb(m * KMAX, 0);
   uint64_t off = 0;
   for (uint64_t t = 0; t < m; ++t) {
     TableDesc& td = tds[t];
@@ -2286,27 +2327,33 @@ obnsl_status obnsl_score_subsets(obnsl_data* d, obnsl_score_kind kind, double es
         return fail(OBNSL_ERR_INVALID_ARGUMENT, "var_ids must be sorted");
       td.cards[i] = d->card[v];
       pb[t * KMAX + i] = d->plane_base[v];
-      cd[t * KMAX + i] = d->card[v];
       cells *= d->card[v];
       if (cells > (1ull << 26)) return fail(OBNSL_ERR_UNSUPPORTED, "table has more than 2^26 cells");
     }
     off += cells;
   }
-  DevBuf<uint32_t> dpb, dcd, dcnt;
+  DevBuf<uint32_t> dpb, dcnt;
   DevBuf<TableDesc> dtd;
   DevBuf<double> dout;
+  uint32_t max_cells = 1;
+  for (uint64_t t = 0; t < m; ++t)
+    max_cells = std::max<uint32_t>(max_cells, (uint32_t)((t + 1 < m ? tds[t + 1].off : off) - tds[t].off));
   HIP_TRY(dpb.upload(pb));
-  HIP_TRY(dcd.upload(cd));
   HIP_TRY(dtd.upload(tds));
   HIP_TRY(dcnt.ensure(std::max<uint64_t>(off, 1)));
   HIP_TRY(dout.ensure(std::max<uint64_t>(m * k, 1)));
   HIP_TRY(hipMemsetAsync(dcnt.p, 0, off * sizeof(uint32_t), d->stream));
-  const uint32_t gx = std::min<uint32_t>((d->wp + 255) / 256, 64);
-  for (uint64_t t = 0; t < m; ++t) {
-    const uint32_t cells = (uint32_t)((t + 1 < m ? tds[t + 1].off : off) - tds[t].off);
-    hipLaunchKernelGGL(count_single_kernel, dim3(gx, std::min<uint32_t>(cells, 1024)), dim3(256),
-                       0, d->stream, d->planes.p, d->wp, k, dpb.p + t * KMAX, dcd.p + t * KMAX,
-                       cells, dcnt.p + tds[t].off, d->ones_plane);
+  // row chunks: about 8192 words each for long lists, more of them when the list
+  // is too short to fill the chip otherwise
+  const uint32_t wblocks = (d->wp + 255) / 256;
+  uint32_t gz = std::max<uint32_t>(1, std::min<uint32_t>(d->wp / 8192, 64));
+  if (m < 64) gz = std::max<uint32_t>(gz, (uint32_t)std::min<uint64_t>(64 / std::max<uint64_t>(m, 1), 64));
+  gz = std::min(gz, wblocks);
+  const uint32_t gy = std::min<uint32_t>(max_cells, m > 64 ? 64u : 1024u);
+  for (uint64_t t0 = 0; t0 < m; t0 += (1u << 30)) {
+    const uint32_t gx = (uint32_t)std::min<uint64_t>(1u << 30, m - t0);
+    hipLaunchKernelGGL(count_list_kernel, dim3(gx, gy, gz), dim3(256), 0, d->stream, d->planes.p,
+                       d->wp, k, dpb.p + t0 * KMAX, dtd.p + t0, dcnt.p, d->ones_plane);
   }
   HIP_TRY(hipGetLastError());
   if (m) {
