@@ -49,6 +49,7 @@ class HotPath:
                          if self.exchange else None)
         self.combined = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
         self._count_views = {}
+        self._count_buf = None
 
     def step(self):
         """One pass, queued asynchronously on the current stream (no host
@@ -89,16 +90,30 @@ class HotPath:
         return self.combined
 
     def _sum_counts(self, size, cells):
-        """All-reduce of the engine's own count table, in place: a tensor that
-        aliases the table's device memory (CUDA array interface)."""
+        """All-reduce of the engine's count table.  In place when torch can alias
+        the table's device memory (CUDA array interface); otherwise through a
+        buffer of torch's own and two device copies."""
+        torch = self.torch
         ptr, cells = self.data.counts_pointer(size)
         view = self._count_views.get((ptr, cells))
         if view is None:
-            view = self.torch.as_tensor(_DeviceInts(ptr, cells), device=self.dev)
-            assert view.data_ptr() == ptr
+            try:
+                view = torch.as_tensor(_DeviceInts(ptr, cells), device=self.dev)
+                if view.data_ptr() != ptr or view.device != self.dev:
+                    view = False
+            except Exception:  # noqa: BLE001  (no array-interface support: take the copying path)
+                view = False
             self._count_views[(ptr, cells)] = view
-        obd.sum_count_table(view)       # disjoint slices, zero elsewhere: the sum is the whole table
-        self.data.counts_mark_summed(size)
+        if view is not False:
+            obd.sum_count_table(view)   # disjoint slices, zero elsewhere: the sum is the whole table
+            self.data.counts_mark_summed(size)
+            return
+        if self._count_buf is None or self._count_buf.numel() < cells:
+            self._count_buf = torch.empty(cells, dtype=torch.int32, device=self.dev)
+        buf = self._count_buf[:cells]
+        self.data.counts_export(size, buf.data_ptr())
+        obd.sum_count_table(buf)
+        self.data.counts_import(size, buf.data_ptr())
 
     @staticmethod
     def to_host(best):
