@@ -419,3 +419,25 @@ def test_sharded_second_size_sums_to_the_whole_table(engine, world):
     assert rel_err(st.max(dim=0).values.cpu().numpy().reshape(T, kmax), want) <= REL
     for d in ranks + [whole]:
         d.close()
+
+
+def test_unsummed_slice_is_forgotten_after_a_new_pack(engine):
+    """A sharded precount whose table is never summed blocks scoring for those
+    row bitmaps only: after the next pack the data set counts and scores as usual."""
+    import oracle
+    from openbnsl_amd import synth
+    cards = [2, 3, 4, 2, 3, 4, 3, 2, 4, 3, 2, 3, 4, 2, 3, 3, 2, 4, 2, 3, 4, 2]
+    codes, card, _, _ = synth.random_bn(cards, 3_000, seed=22)
+    d = engine.Data(codes, card)
+    size, cells = d.precount_sharded(4, 1, 2)
+    assert size == 3 and cells == d.counts_cells(3)
+    with pytest.raises(ValueError, match="one rank's slice"):
+        d.score_all(4)
+    d.pack()
+    assert rel_err(d.score_all(4), oracle.score_all(codes, card, 4, nthreads=4)) <= REL
+    d.pack()
+    d.precount(4)
+    assert rel_err(d.score_all(3), oracle.score_all(codes, card, 3, nthreads=4)) <= REL
+    with pytest.raises(ValueError, match="no count table"):
+        d.counts_cells(7)
+    d.close()
