@@ -12,8 +12,12 @@
  * oracle/_ref by oracle/Makefile) through tests/golden fixtures.  The
  * exhaustive-search DP is pinned only by the reference test's structural
  * criterion, because src/structure_learning/exhaustive_search.cpp cannot be
- * compiled here (it includes a Boost header that this image lacks).  BIC has no
- * reference implementation at all: PARITY UNPINNED for BIC.
+ * compiled here (it includes a Boost header that this image lacks); its optimum
+ * is additionally checked against every DAG on 4-5 nodes in the tests.  BIC has
+ * no reference implementation at all: PARITY UNPINNED for BIC.  Simulated
+ * annealing is not restated here: its checker is the reference's own
+ * simulated_annealing.cpp, compiled into oracle/_ref, and the graphs it returned
+ * (tests/golden).
  */
 #include <math.h>
 #include <stdint.h>
