@@ -117,12 +117,17 @@ DataframeWrapper::DataframeWrapper(const py::object& dataframe) {
     const char* col = base + static_cast<ssize_t>(v) * s1;
     {
       std::unordered_map<std::string, uint32_t> seen;
-      PyObject* last_obj = nullptr;
-      uint32_t last_id = 0;
+      // the cells of a column usually share a few string objects: a small
+      // direct-mapped cache by object address answers those without hashing the
+      // text again (every object stays alive while the array holds it, so an
+      // address names one string for the whole pass)
+      struct Slot { PyObject* obj; uint32_t id; };
+      Slot cache[256] = {};
       for (size_t i = 0; i < num_of_datapoints; ++i) {
         PyObject* o = *reinterpret_cast<PyObject* const*>(col + static_cast<ssize_t>(i) * s0);
-        if (o == last_obj && o) {
-          ids[i] = last_id;
+        Slot& slot = cache[(reinterpret_cast<uintptr_t>(o) >> 4) & 255];
+        if (o && slot.obj == o) {
+          ids[i] = slot.id;
           continue;
         }
         Py_ssize_t len = 0;
@@ -138,8 +143,8 @@ DataframeWrapper::DataframeWrapper(const py::object& dataframe) {
           it = seen.emplace(std::string(s, static_cast<size_t>(len)), labels.size()).first;
           labels.push_back(it->first);
         }
-        ids[i] = last_id = it->second;
-        last_obj = o;
+        ids[i] = it->second;
+        slot = Slot{o, it->second};
       }
     }
     rank_codes(ids, labels, codes.data() + v * num_of_datapoints, val_idx2str[v]);
