@@ -53,7 +53,7 @@ def make_data(spec):
     raise ValueError(spec["gen"])
 
 
-def cpu_baseline(codes, card, names, max_parents, budget_s=20.0):
+def cpu_baseline(codes, card, names, max_parents, budget_s=20.0, data=None):
     """Reference C++ (oracle/_ref) timed single-threaded, as the reference runs
     it, on a bounded sample of size-(max_parents+1) subsets of this workload."""
     import oracle
@@ -74,8 +74,16 @@ def cpu_baseline(codes, card, names, max_parents, budget_s=20.0):
         secs, _ = ref.score_subsets_timed(dfw, probe, 1.0)
         m = int(max(1, min(len(subs_all), budget_s / max(secs, 1e-6))))
         pick = [list(map(int, s)) for s in subs_all[:m]]
-        secs, _ = ref.score_subsets_timed(dfw, pick, 1.0)
+        secs, ref_scores = ref.score_subsets_timed(dfw, pick, 1.0)
+        parity = None
+        if data is not None:
+            # the same tables from the engine (variable ids mapped back to the full matrix)
+            orig = np.array([[cols[i] for i in s] for s in pick], dtype=np.uint32)
+            have = data.score_subsets(orig)
+            want = np.array(ref_scores, dtype=np.float64)
+            parity = float(np.max(np.abs(have - want) / np.abs(want)))
         out = {"value": m * len(pick[0]) / secs, "unit": "scores/s", "cores": 1, "kind": "reference",
+               "parity_max_rel_err": parity, "parity_tables": m,
                "sample": f"{m} size-{len(pick[0])} subsets over {ncols} of the {n} columns, all {codes.shape[1]} rows, "
                          f"reference ContingencyTable + calculate_local_score, {secs:.1f} s"}
     else:
@@ -312,7 +320,7 @@ def main():
         out["simulated_annealing"] = simulated_annealing_wallclock(engine, data, not args.no_cpu_baseline)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.only_hot_path:
         try:
-            base, omp = cpu_baseline(codes, card, names, mp)
+            base, omp = cpu_baseline(codes, card, names, mp, data=data)
             out["cpu_baseline"] = base
             out["cpu_baseline_omp"] = omp
         except Exception as e:  # noqa: BLE001
