@@ -576,23 +576,31 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
     uint64_t ntables, uint32_t tables_per_wg, const uint32_t* __restrict__ card,
     const uint64_t* __restrict__ binom, uint32_t num_rows, int kind, double ess,
     double* __restrict__ G, const double* __restrict__ Gprev, double g0,
-    double* __restrict__ scores, const double* __restrict__ lg_alpha) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t E[];
+    double* __restrict__ scores, const double* __restrict__ lg_alpha, uint32_t e_stride) {
+  // The wavefront works on TWO tables at a time, one per half (32 lanes each):
+  // a table is a chain of dependent loads (descriptors -> table bases -> counts
+  // -> G of the subsets below), and two chains in flight per wave hide more of
+  // that latency than one.  Both halves pass the same barriers; a half without a
+  // table (odd count) idles through them.
+  extern __shared__ __attribute__((aligned(16))) uint32_t E_all[];
   __shared__ SizeView sv[KMAX + 1];
-  __shared__ uint32_t s_vars[KMAX], s_cards[KMAX];
-  __shared__ uint64_t pat_base[1 << KT];  // first counter of the reduced table of a support pattern
+  __shared__ uint32_t s_vars[2][KMAX], s_cards[2][KMAX];
+  __shared__ uint64_t pat_base_all[2][1 << KT];  // first counter of the reduced table of a support pattern
   constexpr uint32_t k = KT;
-  const uint32_t lane = threadIdx.x;
+  const uint32_t half = threadIdx.x >> 5, lane = threadIdx.x & 31;
+  uint32_t* E = E_all + (size_t)half * e_stride;
+  uint64_t* pat_base = pat_base_all[half];
 #pragma unroll
   for (int j = 0; j <= KMAX; ++j)
-    if (lane == (uint32_t)j) sv[j] = views.v[j];
+    if (threadIdx.x == (uint32_t)j) sv[j] = views.v[j];
   const uint64_t t0 = (uint64_t)blockIdx.x * tables_per_wg;
   const uint64_t t1 = min(t0 + (uint64_t)tables_per_wg, ntables);
-  // row group of the first table; consecutive tables advance through the groups
+  // row group of this half's first table; its later tables advance through the groups
+  const uint64_t first = min(t0 + half, ntables - 1);
   uint32_t g = 0, hi = nrgs - 1;
   while (g < hi) {
     const uint32_t mid = (g + hi + 1) >> 1;
-    if (rgs[mid].tbl_start <= t0) g = mid;
+    if (rgs[mid].tbl_start <= first) g = mid;
     else hi = mid - 1;
   }
   RowGroupDesc rg = rgs[g];
@@ -600,136 +608,150 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
   __syncthreads();
   const ColGroupDesc* __restrict__ own_cgs = sv[k].cgs;
 
-  for (uint64_t t = t0; t < t1; ++t) {
-    while (t >= rg.tbl_start + rg.ncolgroups) rg = rgs[++g];
-    const uint32_t gamma = (uint32_t)(t - rg.tbl_start);
-    // (fixed-trip loops guarded by i < k keep these small arrays in registers)
+  for (uint64_t tp = t0; tp < t1; tp += 2) {
+    const uint64_t t = tp + half;
+    const bool active = t < t1;
     uint32_t vars[KMAX], cards[KMAX];
     float inv_card[KMAX];
-    ColGroupDesc cg;
-    if (kc > 0) cg = own_cgs[gamma];
+    uint32_t cells = 1, gamma = 0;
 #pragma unroll
     for (int i = 0; i < KMAX; ++i) {
       vars[i] = 0;
-      if (i < KSIDE && i < (int)kc) vars[i] = cg.vars[i];
-#pragma unroll
-      for (int j = 0; j < KSIDE; ++j)
-        if (i == (int)kc + j && j < (int)kr) vars[i] = rg.vars[j];
-    }
-    uint32_t cells = 1;
-#pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
       cards[i] = 1;
       inv_card[i] = 1.0f;
-      if (i < (int)k) {
-        cards[i] = card[vars[i]];
-        inv_card[i] = 1.0f / (float)cards[i];
-        cells *= cards[i];
-      }
     }
-    // where the reduced table of each non-empty support pattern starts: the table
-    // of T (|T| = j) lives in size j's layout, row side = its kr_j largest variables
-    for (uint32_t pat = lane + 1; pat < (1u << k); pat += 64) {
-      const SizeView s = sv[__popc(pat)];
-      uint64_t colrank = 0, rowrank = 0;
-      uint32_t mred = 1, p = 0;
+    if (active) {
+      while (t >= rg.tbl_start + rg.ncolgroups) rg = rgs[++g];
+      gamma = (uint32_t)(t - rg.tbl_start);
+      // (fixed-trip loops guarded by i < k keep these small arrays in registers)
+      ColGroupDesc cg;
+      if (kc > 0) cg = own_cgs[gamma];
 #pragma unroll
       for (int i = 0; i < KMAX; ++i) {
-        if (i >= (int)k || !(pat >> i & 1)) continue;
-        ++p;
-        if (p <= s.kc) {
-          colrank += binom[vars[i] * (KMAX + 1) + p];
-        } else {
-          rowrank += binom[vars[i] * (KMAX + 1) + (p - s.kc)];
-          mred *= cards[i] - 1;
+        if (i < KSIDE && i < (int)kc) vars[i] = cg.vars[i];
+#pragma unroll
+        for (int j = 0; j < KSIDE; ++j)
+          if (i == (int)kc + j && j < (int)kr) vars[i] = rg.vars[j];
+      }
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i) {
+        if (i < (int)k) {
+          cards[i] = card[vars[i]];
+          inv_card[i] = 1.0f / (float)cards[i];
+          cells *= cards[i];
         }
       }
-      const uint32_t col_before = s.kc ? s.cgs[colrank].col_before : 0;
-      pat_base[pat] = s.rowoff[rowrank] + (uint64_t)col_before * mred;
+      // where the reduced table of each non-empty support pattern starts: the table
+      // of T (|T| = j) lives in size j's layout, row side = its kr_j largest variables
+      for (uint32_t pat = lane + 1; pat < (1u << k); pat += 32) {
+        const SizeView s = sv[__popc(pat)];
+        uint64_t colrank = 0, rowrank = 0;
+        uint32_t mred = 1, p = 0;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+          if (i >= (int)k || !(pat >> i & 1)) continue;
+          ++p;
+          if (p <= s.kc) {
+            colrank += binom[vars[i] * (KMAX + 1) + p];
+          } else {
+            rowrank += binom[vars[i] * (KMAX + 1) + (p - s.kc)];
+            mred *= cards[i] - 1;
+          }
+        }
+        const uint32_t col_before = s.kc ? s.cgs[colrank].col_before : 0;
+        pat_base[pat] = s.rowoff[rowrank] + (uint64_t)col_before * mred;
+      }
     }
     __syncthreads();
     // E(e): digit 0 = "any".  Within a pattern the counter index is the mixed-radix
     // number of the non-zero digits (radix r - 1, first variable most significant).
-    for (uint32_t cell = lane; cell < cells; cell += 64) {
-      uint32_t rem = cell, pat = 0, key = 0, mul = 1;
+    if (active) {
+      for (uint32_t cell = lane; cell < cells; cell += 32) {
+        uint32_t rem = cell, pat = 0, key = 0, mul = 1;
 #pragma unroll
-      for (int i = KMAX - 1; i >= 0; --i) {
-        if (i >= (int)k) continue;
-        const uint32_t qt = fast_div(rem, inv_card[i]);
-        const uint32_t e = rem - qt * cards[i];
-        rem = qt;
-        if (e) {
-          pat |= 1u << i;
-          key += (e - 1) * mul;
-          mul *= cards[i] - 1;
+        for (int i = KMAX - 1; i >= 0; --i) {
+          if (i >= (int)k) continue;
+          const uint32_t qt = fast_div(rem, inv_card[i]);
+          const uint32_t e = rem - qt * cards[i];
+          rem = qt;
+          if (e) {
+            pat |= 1u << i;
+            key += (e - 1) * mul;
+            mul *= cards[i] - 1;
+          }
         }
+        E[cell] = pat ? sv[__popc(pat)].red[pat_base[pat] + key] : num_rows;
       }
-      E[cell] = pat ? sv[__popc(pat)].red[pat_base[pat] + key] : num_rows;
     }
     __syncthreads();
     uint32_t w = 1;
 #pragma unroll
     for (int i = KMAX - 1; i >= 0; --i) {
       if (i >= (int)k) continue;
-      const uint32_t r = cards[i];
-      const uint32_t lines = fast_div(cells, inv_card[i]);
-      const float inv_w = 1.0f / (float)w;
-      for (uint32_t l = lane; l < lines; l += 64) {
-        const uint32_t h = fast_div(l, inv_w), lo_ = l - h * w;
-        const uint32_t base = h * (r * w) + lo_;
-        uint32_t sum = 0;
-        for (uint32_t st = 1; st < r; ++st) sum += E[base + st * w];
-        E[base] -= sum;
+      if (active) {
+        const uint32_t r = cards[i];
+        const uint32_t lines = fast_div(cells, inv_card[i]);
+        const float inv_w = 1.0f / (float)w;
+        for (uint32_t l = lane; l < lines; l += 32) {
+          const uint32_t h = fast_div(l, inv_w), lo_ = l - h * w;
+          const uint32_t base = h * (r * w) + lo_;
+          uint32_t sum = 0;
+          for (uint32_t st = 1; st < r; ++st) sum += E[base + st * w];
+          E[base] -= sum;
+        }
+        w *= r;
       }
       __syncthreads();
-      w *= r;
     }
     const uint64_t rank = rg.rank_part + gamma;
     double gsum = 0.0;
-    if (kind == OBNSL_SCORE_BDEU) {
-      const double a = ess / (double)cells;
-      const double lg_a = lg_alpha[cells];  // lgamma(a): the same for every table of this size
-      for (uint32_t c = lane; c < cells; c += 64) {
-        const uint32_t nc = E[c];
-        if (nc) gsum += lgamma_pos((double)nc + a) - lg_a;
-      }
-    } else {
-      for (uint32_t c = lane; c < cells; c += 64) {
-        const uint32_t nc = E[c];
-        if (nc) gsum += (double)nc * log((double)nc);
+    if (active) {
+      if (kind == OBNSL_SCORE_BDEU) {
+        const double a = ess / (double)cells;
+        const double lg_a = lg_alpha[cells];  // lgamma(a): the same for every table of this size
+        for (uint32_t c = lane; c < cells; c += 32) {
+          const uint32_t nc = E[c];
+          if (nc) gsum += lgamma_pos((double)nc + a) - lg_a;
+        }
+      } else {
+        for (uint32_t c = lane; c < cells; c += 32) {
+          const uint32_t nc = E[c];
+          if (nc) gsum += (double)nc * log((double)nc);
+        }
       }
     }
-    gsum = wave_sum(gsum);
-    if (lane == 0) G[rank] = gsum;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o);  // within the half
+    if (active && lane == 0) G[rank] = gsum;
     if (scores != nullptr) {
 #pragma unroll
       for (int i = 0; i < KMAX; ++i)
         if (lane == (uint32_t)i && i < (int)k) {
-          s_vars[i] = vars[i];
-          s_cards[i] = cards[i];
+          s_vars[half][i] = vars[i];
+          s_cards[half][i] = cards[i];
         }
       __syncthreads();
-      if (lane < k) {
+      if (active && lane < k) {
         double gp = g0;
         if (k > 1) {
           uint64_t sub = 0;
           uint32_t pos = 1;
           for (uint32_t j = 0; j < k; ++j) {
             if (j == lane) continue;
-            sub += binom[s_vars[j] * (KMAX + 1) + pos];
+            sub += binom[s_vars[half][j] * (KMAX + 1) + pos];
             ++pos;
           }
           gp = Gprev[sub];
         }
         double sc = gsum - gp;
         if (kind == OBNSL_SCORE_BIC) {
-          const uint32_t r = s_cards[lane];
+          const uint32_t r = s_cards[half][lane];
           sc -= 0.5 * log((double)num_rows) * (double)(cells / r) * (double)(r - 1);
         }
         scores[rank * k + lane] = sc;
       }
     }
-    __syncthreads();  // E, pat_base and s_vars are reused by the next table
+    __syncthreads();  // E, pat_base and s_vars are reused by the next pair of tables
   }
 }
 
@@ -1600,14 +1622,16 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
       const char* e = std::getenv("OBNSL_TABLES_PER_WG");
       return e ? (uint32_t)std::atoi(e) : 0u;
     }();
-    uint32_t tpw = (uint32_t)std::min<uint64_t>(2, std::max<uint64_t>(1, b->ntables / 4096));
+    uint32_t tpw = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(2, b->ntables / 2048));
     if (tpw_env) tpw = tpw_env;
+    tpw = (tpw + 1) & ~1u;  // a wavefront takes its tables two at a time
     const uint32_t grid = (uint32_t)((b->ntables + tpw - 1) / tpw);
+    const uint32_t e_stride = (uint32_t)((max_cells + 3) & ~3ull);
 #define OBNSL_LAUNCH_SCORER(KT)                                                                  \
   hipLaunchKernelGGL((score_reduced_kernel<KT>), dim3(grid), dim3(64),                           \
-                     (size_t)max_cells * sizeof(uint32_t), d->stream, views, b->rgs.p, b->nrgs,  \
-                     b->ntables, tpw, d->d_card.p, d->d_binom.p, (uint32_t)d->N, (int)kind, ess, \
-                     plan->G.p, gprev, g0, scores, lg_alpha)
+                     (size_t)2 * e_stride * sizeof(uint32_t), d->stream, views, b->rgs.p,        \
+                     b->nrgs, b->ntables, tpw, d->d_card.p, d->d_binom.p, (uint32_t)d->N,        \
+                     (int)kind, ess, plan->G.p, gprev, g0, scores, lg_alpha, e_stride)
     switch (k) {
       case 1: OBNSL_LAUNCH_SCORER(1); break;
       case 2: OBNSL_LAUNCH_SCORER(2); break;
