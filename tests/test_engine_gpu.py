@@ -441,3 +441,30 @@ def test_unsummed_slice_is_forgotten_after_a_new_pack(engine):
     with pytest.raises(ValueError, match="no count table"):
         d.counts_cells(7)
     d.close()
+
+
+def test_extreme_priors_and_a_very_wide_variable(engine):
+    """BDeu with tiny and huge equivalent sample sizes (lgamma arguments from
+    1e-6 up to 1e6), and a 200-state variable next to binary ones (tables of
+    200..1600 cells: LDS expansion, histogram path, single-table calls)."""
+    import oracle
+    rng = np.random.default_rng(31)
+    N = 50_000
+    card = np.array([2, 200, 3, 2, 4], dtype=np.uint32)
+    codes = np.stack([rng.integers(0, c, size=N) for c in card]).astype(np.uint8)
+    codes[1, :4000] = 7                        # a heavy cell among many nearly empty ones
+    d = engine.Data(codes, card)
+    for ess in (1e-3, 1.0, 1e3):
+        for k in (1, 2, 3):
+            want = oracle.score_all(codes, card, k, oracle.BDEU, ess, nthreads=4)
+            have = d.score_all(k, engine.BDEU, ess)
+            assert rel_err(have, want) <= REL, (ess, k)
+    for vs in ([1], [0, 1], [1, 2, 4], [0, 1, 2, 3]):
+        assert np.array_equal(d.count(vs), oracle.count(codes, card, vs))
+    sub = np.array([[0, 1, 4], [1, 2, 3]], dtype=np.uint32)
+    have = d.score_subsets(sub, engine.BDEU, 1e-3)
+    for t, vs in enumerate(sub):
+        cnt = oracle.count(codes, card, vs)
+        want = [oracle.local_score(cnt, card[vs], ci, oracle.BDEU, 1e-3) for ci in range(3)]
+        assert rel_err(have[t], want) <= REL
+    d.close()
