@@ -62,6 +62,16 @@ obnsl_status obnsl_internal::fail(obnsl_status st, const std::string& msg) { ret
 
 namespace {
 
+// Which contraction kernel counts the tables: the matrix-core form (default) or
+// the vector-ALU and/popcount form (OBNSL_GEMM=valu; kept for comparison runs).
+bool use_mfma_gemm() {
+  static const bool on = [] {
+    const char* e = std::getenv("OBNSL_GEMM");
+    return !(e && std::strcmp(e, "valu") == 0);
+  }();
+  return on;
+}
+
 #define HIP_TRY(expr)                                                                  \
   do {                                                                                 \
     hipError_t e_ = (expr);                                                            \
@@ -319,6 +329,238 @@ __global__ __launch_bounds__(256, TT == 8 ? 2 : 1) void bitgemm_kernel(
       }
     }
   }
+}
+
+// ------------------------------------------------------------------ bit-GEMM on the matrix cores
+// The same contraction with v_mfma_scale_f32_32x32x64_f8f6f4 on FP4 (e2m1)
+// operands.  A 32-bit word of 32 sample bits is used as eight FP4 nibbles four
+// times over: w & 0x11111111, w & 0x22222222, w & 0x44444444 are words whose
+// nibbles are 0 or 0b0001 / 0b0010 / 0b0100 = 0.5 / 1.0 / 2.0 in e2m1, and
+// (w >> 3) & 0x11111111 brings the fourth bit of every nibble (the e2m1 sign)
+// down to 0.5 as well.  The block scales (E8M0, one byte per operand) of each of
+// the four instructions make the product of two set bits exactly 1.0, so the f32
+// accumulator holds the integer count, exact while it stays below 2^24 (the
+// host bounds the samples per workgroup accordingly).  The contraction is a sum
+// over samples: which sample sits at which K position does not matter as long as
+// A and B agree, and both are built by the same code from the same words.
+//
+// One instruction does 32 x 32 x 64 cell-samples in ~16 ns per SIMD (measured),
+// 6.5 x the and/popcount pair stream of the vector ALU.  Operand build: 5 vector
+// instructions per 32 rows x 32 samples of an operand, amortised over the
+// wave's column blocks.
+//
+// A workgroup (4 waves) owns a 128 x 128 tile of C; wave w owns rows 32 w .. 32 w
+// + 31 and the tile's first JM 32-column blocks (JM < 4 on the staircase edge:
+// every wave then does the same, smaller, amount of work).  LDS holds the
+// ANDed sample words exactly as in the vector-ALU kernel; a lane reads 16 bytes
+// (128 samples of its row) per operand and round.
+typedef int obnsl_v8i __attribute__((ext_vector_type(8)));
+typedef float obnsl_v16f __attribute__((ext_vector_type(16)));
+
+template <int J>
+__device__ __forceinline__ obnsl_v8i fp4_operand(const uint4 w) {
+  obnsl_v8i f;
+  if constexpr (J < 3) {
+    constexpr uint32_t m = 0x11111111u << J;
+    f[0] = (int)(w.x & m);
+    f[1] = (int)(w.y & m);
+    f[2] = (int)(w.z & m);
+    f[3] = (int)(w.w & m);
+  } else {
+    f[0] = (int)((w.x >> 3) & 0x11111111u);
+    f[1] = (int)((w.y >> 3) & 0x11111111u);
+    f[2] = (int)((w.z >> 3) & 0x11111111u);
+    f[3] = (int)((w.w >> 3) & 0x11111111u);
+  }
+  f[4] = f[5] = f[6] = f[7] = 0;
+  return f;
+}
+
+template <int J>
+__device__ __forceinline__ obnsl_v16f fp4_mfma(const obnsl_v8i a, const obnsl_v8i b, const obnsl_v16f c) {
+  // E8M0 scale bytes: 0.5-valued nibbles (J = 0, 3) x 2, 1.0 (J = 1) x 1, 2.0 (J = 2) x 1/2
+  constexpr int sc = (J == 1) ? 0x7f7f7f7f : (J == 2) ? 0x7e7e7e7e : (int)0x80808080u;
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, sc, 0, sc);
+}
+
+// One (rd, J) block: the A operand once, then per column block its B operand and
+// the instruction.  The scheduling fences keep the compiler from building the
+// operands of all four J up front (80 live registers, one wave per SIMD less).
+template <int JM, int J>
+__device__ __forceinline__ void mfma_block(const uint4 wa, const uint4 (&wb)[JM], obnsl_v16f (&acc)[JM]) {
+  const obnsl_v8i a = fp4_operand<J>(wa);
+#pragma unroll
+  for (int j = 0; j < JM; ++j) acc[j] = fp4_mfma<J>(a, fp4_operand<J>(wb[j]), acc[j]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int JM>
+__device__ __forceinline__ void tile_mfma(const uint32_t* __restrict__ sA,
+                                          const uint32_t* __restrict__ sB, uint32_t arow,
+                                          uint32_t brow, uint32_t hoff, obnsl_v16f (&acc)[JM]) {
+#pragma unroll 1
+  for (int rd = 0; rd < KCW / 8; ++rd) {
+    const uint4 wa = *reinterpret_cast<const uint4*>(&sA[arow * LDS_STRIDE + rd * 8 + hoff]);
+    uint4 wb[JM];
+#pragma unroll
+    for (int j = 0; j < JM; ++j)
+      wb[j] = *reinterpret_cast<const uint4*>(&sB[(brow + 32 * j) * LDS_STRIDE + rd * 8 + hoff]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block<JM, 0>(wa, wb, acc);
+    mfma_block<JM, 1>(wa, wb, acc);
+    mfma_block<JM, 2>(wa, wb, acc);
+    mfma_block<JM, 3>(wa, wb, acc);
+  }
+}
+
+constexpr int MFMA_TILE = 128;        // tile edge of the matrix-core kernel
+constexpr uint32_t MFMA_MAX_STEPS = (1u << 24) / (KCW * 32);  // samples per workgroup < 2^24
+
+// Everything after the tile is known, for one value of JM (a template
+// parameter of the whole loop nest, so that the accumulators live in the
+// accumulator registers from the first step to the epilogue).
+template <int KR, int KC, int JM>
+__device__ __forceinline__ void mfma_tile_body(
+    uint32_t* __restrict__ smem, const uint32_t* __restrict__ planes, uint32_t wp,
+    const RowDesc* __restrict__ rows, uint32_t nrows, const ColDesc* __restrict__ cols,
+    uint32_t ncols_total, uint32_t row0, uint32_t col0, uint32_t* __restrict__ counts,
+    uint32_t step_lo, uint32_t step_hi, bool atomics, bool probe_noload) {
+  constexpr int TB = MFMA_TILE;
+  constexpr int NP = TB / 32;  // staging passes: 256 threads fill 32 slab rows per pass
+  const uint32_t tid = threadIdx.x;
+  // staging role: 8 threads cover one 32-word slab row with one uint4 each
+  const uint32_t q = tid & 7, rl = tid >> 3;
+  uint32_t aoff[NP][KR], boff[NP][KC];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const uint32_t r = min(row0 + rl + 32 * p, nrows - 1);
+    const uint32_t c = min(col0 + rl + 32 * p, ncols_total - 1);
+#pragma unroll
+    for (int j = 0; j < KR; ++j) aoff[p][j] = rows[r].plane[j] * wp + q * 4;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) boff[p][j] = cols[c].plane[j] * wp + q * 4;
+  }
+  const uint32_t st_off = rl * LDS_STRIDE + q * 4;
+
+  // compute role: lane (lr, h) of wave wv holds row 32 wv + lr of A and column
+  // 32 j + lr of B, samples 128 h .. 128 h + 127 of each 256-sample round
+  const uint32_t lane = tid & 63, wv = tid >> 6;
+  const uint32_t lr = lane & 31, h4 = (lane >> 5) * 4;
+  obnsl_v16f acc[JM];
+#pragma unroll
+  for (int j = 0; j < JM; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+  uint4 ga[NP][KR], gb[NP][KC];
+
+  auto issue_loads = [&](uint32_t step) {
+    const uint32_t w0 = step * KCW;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+      for (int j = 0; j < KR; ++j)
+        ga[p][j] = *reinterpret_cast<const uint4*>(planes + aoff[p][j] + w0);
+#pragma unroll
+      for (int j = 0; j < KC; ++j)
+        gb[p][j] = *reinterpret_cast<const uint4*>(planes + boff[p][j] + w0);
+    }
+  };
+  auto write_slab = [&](uint32_t buf) {
+    uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
+    uint32_t* sB = sA + TB * LDS_STRIDE;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      uint4 va = ga[p][0], vb = gb[p][0];
+#pragma unroll
+      for (int j = 1; j < KR; ++j) va = and4(va, ga[p][j]);
+#pragma unroll
+      for (int j = 1; j < KC; ++j) vb = and4(vb, gb[p][j]);
+      *reinterpret_cast<uint4*>(&sA[st_off + 32 * p * LDS_STRIDE]) = va;
+      *reinterpret_cast<uint4*>(&sB[st_off + 32 * p * LDS_STRIDE]) = vb;
+    }
+  };
+
+  if (step_lo < step_hi) {
+    issue_loads(step_lo);
+    write_slab(0);
+  }
+  __syncthreads();
+  for (uint32_t step = step_lo; step < step_hi; ++step) {
+    const uint32_t buf = (step - step_lo) & 1;
+    const bool more = step + 1 < step_hi && !probe_noload;
+    if (more) issue_loads(step + 1);
+    const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
+    const uint32_t* sB = sA + TB * LDS_STRIDE;
+    tile_mfma<JM>(sA, sB, wv * 32 + lr, lr, h4, acc);
+    if (more) write_slab(buf ^ 1);
+    __syncthreads();
+  }
+
+  // The slabs are dead now (the loop ends on a barrier): park the tile's row
+  // descriptors in LDS, one per thread, instead of 16 dependent global loads per lane.
+  uint64_t* s_base = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* s_M = smem + 2 * TB;
+  uint32_t* s_nc = smem + 3 * TB;
+  if (tid < (uint32_t)TB) {
+    const uint32_t r = row0 + tid;
+    uint32_t nc = 0;
+    if (r < nrows) {
+      const RowDesc rd = rows[r];
+      s_base[tid] = rd.out_base;
+      s_M[tid] = rd.M;
+      nc = rd.ncols;
+    }
+    s_nc[tid] = nc;  // 0 for a row past the end: no column is valid
+  }
+  __syncthreads();
+  // C/D layout of the 32 x 32 forms: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t rt = wv * 32 + (i & 3) + 8 * (i >> 2) + h4;
+    const uint32_t nc = s_nc[rt], M = s_M[rt];
+    const uint64_t base = s_base[rt];
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const uint32_t c = col0 + 32 * j + lr;
+      if (c >= nc) continue;
+      const uint32_t v = (uint32_t)acc[j][i];
+      uint32_t* dst = counts + base + (uint64_t)c * M;
+      if (atomics) {
+        if (v) atomicAdd(dst, v);
+      } else {
+        *dst = v;
+      }
+    }
+  }
+}
+
+template <int KR, int KC>
+__global__ __launch_bounds__(256) void bitgemm_mfma_kernel(
+    const uint32_t* __restrict__ planes, uint32_t wp, const RowDesc* __restrict__ rows,
+    uint32_t nrows, const ColDesc* __restrict__ cols, uint32_t ncols_total,
+    const uint2* __restrict__ items, uint32_t nitems, uint32_t* __restrict__ counts,
+    uint32_t steps_total, uint32_t steps_per_split, int use_atomics) {
+  // two slabs of A and of B (one array: see bitgemm_kernel)
+  __shared__ __attribute__((aligned(16))) uint32_t smem[2 * 2 * MFMA_TILE * LDS_STRIDE];
+  const uint32_t item_id = blockIdx.x % nitems;
+  const uint32_t split = blockIdx.x / nitems;
+  const uint2 it = items[item_id];
+  const uint32_t row0 = it.x * MFMA_TILE, col0 = it.y * MFMA_TILE;
+  const uint32_t lim = rows[min(row0 + MFMA_TILE, nrows) - 1].ncols;  // the tile's last row has the most
+  const uint32_t jm = (use_atomics & 2) ? 4u : lim > col0 ? min((lim - col0 + 31) / 32, 4u) : 1u;
+  const uint32_t step_lo = split * steps_per_split;
+  const uint32_t step_hi = min(step_lo + steps_per_split, steps_total);
+  const bool atomics = (use_atomics & 1) != 0;
+#define OBNSL_MFMA_BODY(JM)                                                                       \
+  mfma_tile_body<KR, KC, JM>(smem, planes, wp, rows, nrows, cols, ncols_total, row0, col0, counts, \
+                             step_lo, step_hi, atomics, (use_atomics & 4) != 0)
+  switch (jm) {  // uniform over the workgroup
+    case 1: OBNSL_MFMA_BODY(1); break;
+    case 2: OBNSL_MFMA_BODY(2); break;
+    case 3: OBNSL_MFMA_BODY(3); break;
+    default: OBNSL_MFMA_BODY(4); break;
+  }
+#undef OBNSL_MFMA_BODY
 }
 
 // ------------------------------------------------------------------ single table
@@ -1124,6 +1366,7 @@ struct Plan {
   uint32_t k = 0, kr = 0, kc = 0;
   bool reduced = false;         // rows/columns cover states 1..r-1 only (see score_reduced_kernel)
   uint32_t tile = 128;          // C tile edge of the bit-GEMM launches of this plan
+  bool mfma = false;            // counted by bitgemm_mfma_kernel (128 x 128 tiles, 32-column blocks)
   DevBuf<ColDesc> cols;
   DevBuf<ColGroupDesc> cgs;
   uint32_t ncols_total = 0;
@@ -1319,15 +1562,16 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     for (size_t g = 0; g < rsub.size(); ++g) row0[g + 1] = row0[g] + Ms[g];
     static const uint64_t edge = [] {
       const char* e = std::getenv("OBNSL_TILE");
-      return e && std::atoi(e) == 128 ? 128u : 64u;
+      return use_mfma_gemm() ? (uint64_t)MFMA_TILE : e && std::atoi(e) == 128 ? 128u : 64u;
     }();
+    const uint64_t cgroup = use_mfma_gemm() ? 32 : 16;  // columns the kernel skips by
     auto range_cost = [&](size_t lo, size_t hi) {
       uint64_t c = 0;
       size_t g = lo;
       for (uint64_t r = row0[lo]; r < row0[hi]; r += edge) {
         const uint64_t last = std::min<uint64_t>(r + edge, row0[hi]) - 1;
         while (row0[g + 1] <= last) ++g;
-        c += edge * (((uint64_t)ncols_below[rsub[g][0]] + 15) / 16 * 16);
+        c += edge * (((uint64_t)ncols_below[rsub[g][0]] + cgroup - 1) / cgroup * cgroup);
       }
       return c;
     };
@@ -1448,7 +1692,8 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
       const char* e = std::getenv("OBNSL_TILE");
       return e ? std::atoi(e) : 0;
     }();
-    plan->tile = force_tile == 128 ? 128 : 64;
+    plan->mfma = use_mfma_gemm();
+    plan->tile = plan->mfma ? MFMA_TILE : force_tile == 128 ? 128 : 64;
     make_tiles(plan->tile, tiles);
     std::stable_sort(tiles.begin(), tiles.end(),
                      [](const std::pair<uint32_t, uint2>& a, const std::pair<uint32_t, uint2>& b) {
@@ -1496,7 +1741,11 @@ obnsl_status resolve_events(obnsl_data* d) {
 template <int KR, int KC>
 void launch_bitgemm(obnsl_data* d, const Plan* p, const Batch* b, uint32_t* counts, uint32_t grid,
                     uint32_t steps_total, uint32_t steps_per_split, int atomics) {
-  if (p->tile == 128)
+  if (p->mfma)
+    hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC>), dim3(grid), dim3(256), 0, d->count_stream(),
+                       d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
+                       b->items.p, b->nitems, counts, steps_total, steps_per_split, atomics);
+  else if (p->tile == 128)
     hipLaunchKernelGGL((bitgemm_kernel<KR, KC, 8>), dim3(grid), dim3(256), 0, d->count_stream(),
                        d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
                        b->items.p, b->nitems, counts, steps_total, steps_per_split, atomics);
@@ -1515,19 +1764,23 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, const Batch* b, uint32_t* c
   // (workgroups of equal length run in rounds of 2 per CU; many short ones keep
   // the last round from idling most of the chip)
   uint32_t ksplit = 1;
-  static const uint32_t want = [] {
+  static const uint32_t want_env = [] {
     const char* e = std::getenv("OBNSL_TARGET_WGS");
-    return e ? (uint32_t)std::atoi(e) : 8192u;
+    return e ? (uint32_t)std::atoi(e) : 0u;
   }();
+  // the matrix-core kernel runs two 128 x 128 workgroups per CU: a few rounds of
+  // 512 are enough, and every extra split adds the whole table in atomics
+  const uint32_t want = want_env ? want_env : plan->mfma ? 2048u : 8192u;
   static const uint32_t min_sps = [] {
     const char* e = std::getenv("OBNSL_MIN_SPS");
     return e ? std::max(1u, (uint32_t)std::atoi(e)) : 8u;
   }();
   const uint32_t max_split = std::max<uint32_t>(1, steps_total / min_sps);
   if (b->nitems < want) ksplit = std::min<uint32_t>((want + b->nitems - 1) / b->nitems, max_split);
-  const uint32_t sps = (steps_total + ksplit - 1) / ksplit;
+  uint32_t sps = (steps_total + ksplit - 1) / ksplit;
+  if (plan->mfma) sps = std::min(sps, MFMA_MAX_STEPS);  // f32 accumulators stay exact below 2^24
   ksplit = (steps_total + sps - 1) / sps;
-  static const int nojskip = std::getenv("OBNSL_NO_JSKIP") ? 2 : 0;
+  static const int nojskip = (std::getenv("OBNSL_NO_JSKIP") ? 2 : 0) | (std::getenv("OBNSL_PROBE_NOLOAD") ? 4 : 0);
   const int atomics = (ksplit > 1 ? 1 : 0) | nojskip;
   if ((atomics & 1) && !prezeroed)
     HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
@@ -2193,7 +2446,7 @@ obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_
     st = build_plan(d, kmax - 1, 0, 1, true, &full);
     if (st != OBNSL_OK) return st;
     if (shard_lower && top_is_requested && num_shards > 1 &&
-        full->total_items >= 2ull * num_shards && full->counted_epoch != d->epoch) {
+        full->total_items >= num_shards && full->counted_epoch != d->epoch) {
       // this rank's slice only, written at its place in the whole table; the
       // rest stays zero and the caller sums the tables of all ranks
       Plan* part = nullptr;

@@ -1,0 +1,203 @@
+// mfma_probe.hip -- development probe (not part of the library).
+//
+// 1. Exactness and operand layout of v_mfma_scale_f32_32x32x64_f8f6f4 with FP4
+//    (e2m1) operands built from sample BITS by masking: a 32-bit word of 32
+//    sample bits is split into four words of eight nibbles each,
+//    (w >> j) & 0x11111111 ... expressed without the shift for j = 0, 1, 2 as
+//    w & (0x11111111 << j), whose nibbles are 0b0001 / 0b0010 / 0b0100 =
+//    0.5 / 1.0 / 2.0 in e2m1; the block scales (E8M0) bring every product of
+//    two set bits to exactly 1.0.  The contraction is a sum over samples, so any
+//    assignment of samples to K positions is fine as long as A and B use the same.
+// 2. Issue rate of that instruction and of v_mfma_i32_32x32x32_i8.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_probe.hip -o /tmp/mfma_probe
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define CHECK(x)                                                              \
+  do {                                                                        \
+    hipError_t e_ = (x);                                                      \
+    if (e_ != hipSuccess) {                                                   \
+      std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));            \
+      std::exit(1);                                                           \
+    }                                                                         \
+  } while (0)
+
+__device__ __forceinline__ v8i frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  v8i f = {(int)a, (int)b, (int)c, (int)d, 0, 0, 0, 0};
+  return f;
+}
+
+// C[32][32] = popcount(A[r] & B[c]) over `words` 32-bit words per row
+// (words a multiple of 8); one wavefront.
+__global__ void count_fp4(const uint32_t* A, const uint32_t* B, uint32_t words, uint32_t* C) {
+  const uint32_t l = threadIdx.x, r = l & 31, h = l >> 5;
+  v16f acc = {0};
+  for (uint32_t w0 = 0; w0 < words; w0 += 8) {
+    const uint32_t* pa = A + r * words + w0 + 4 * h;
+    const uint32_t* pb = B + r * words + w0 + 4 * h;
+    const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3];
+    const uint32_t b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
+    const uint32_t m0 = 0x11111111u, m1 = 0x22222222u, m2 = 0x44444444u;
+    // nibble 0b0001 = 0.5: scale 2 on each side (E8M0 128)
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+        frag(a0 & m0, a1 & m0, a2 & m0, a3 & m0), frag(b0 & m0, b1 & m0, b2 & m0, b3 & m0), acc, 4, 4,
+        0, 0x80808080, 0, 0x80808080);
+    // nibble 0b0010 = 1.0
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+        frag(a0 & m1, a1 & m1, a2 & m1, a3 & m1), frag(b0 & m1, b1 & m1, b2 & m1, b3 & m1), acc, 4, 4,
+        0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    // nibble 0b0100 = 2.0: scale 1/2 on each side (E8M0 126)
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+        frag(a0 & m2, a1 & m2, a2 & m2, a3 & m2), frag(b0 & m2, b1 & m2, b2 & m2, b3 & m2), acc, 4, 4,
+        0, 0x7e7e7e7e, 0, 0x7e7e7e7e);
+    // bit 3 of a nibble is the sign: shift it down to 0b0001
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+        frag((a0 >> 3) & m0, (a1 >> 3) & m0, (a2 >> 3) & m0, (a3 >> 3) & m0),
+        frag((b0 >> 3) & m0, (b1 >> 3) & m0, (b2 >> 3) & m0, (b3 >> 3) & m0), acc, 4, 4, 0, 0x80808080,
+        0, 0x80808080);
+  }
+  // C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  for (int reg = 0; reg < 16; ++reg) {
+    const uint32_t row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    C[row * 32 + r] = (uint32_t)acc[reg];
+  }
+}
+
+// The same with the int8 form: every sample bit becomes a 0/1 byte.
+__global__ void count_i8(const uint32_t* A, const uint32_t* B, uint32_t words, uint32_t* C) {
+  const uint32_t l = threadIdx.x, r = l & 31, h = l >> 5;
+  v16i acc = {0};
+  for (uint32_t w0 = 0; w0 < words; ++w0) {
+    // lane half h takes bits 16 h .. 16 h + 15 of the word: four nibbles -> four words of bytes
+    const uint32_t a = A[r * words + w0] >> (16 * h), b = B[r * words + w0] >> (16 * h);
+    v4i fa, fb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = (int)((((a >> (4 * i)) & 15u) * 0x204081u) & 0x01010101u);
+      fb[i] = (int)((((b >> (4 * i)) & 15u) * 0x204081u) & 0x01010101u);
+    }
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, acc, 0, 0, 0);
+  }
+  for (int reg = 0; reg < 16; ++reg) {
+    const uint32_t row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    C[row * 32 + r] = (uint32_t)acc[reg];
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void rate_kernel(float* out, int iters, uint32_t seed) {
+  const uint32_t l = threadIdx.x;
+  uint32_t x = seed * 2654435761u + l * 40503u + blockIdx.x;
+  v8i fa = {(int)(x & 0x22222222u), (int)((x * 3) & 0x22222222u), (int)((x * 5) & 0x22222222u),
+            (int)((x * 7) & 0x22222222u), 0, 0, 0, 0};
+  v8i fb = {(int)((x * 11) & 0x22222222u), (int)((x * 13) & 0x22222222u), (int)((x * 17) & 0x22222222u),
+            (int)((x * 19) & 0x22222222u), 0, 0, 0, 0};
+  if constexpr (MODE == 0 || MODE == 2) {
+    v16f a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+    for (int i = 0; i < iters; ++i) {
+      if constexpr (MODE == 0) {
+        a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb, a0, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb, a1, 4, 4, 0, 0x80808080, 0, 0x7e7e7e7e);
+        a2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb, fa, a2, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        a3 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb, fa, a3, 4, 4, 0, 0x7e7e7e7e, 0, 0x80808080);
+      } else {  // scales 0, 0: the unscaled instruction
+        a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb, a0, 4, 4, 0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb, a1, 4, 4, 0, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb, fa, a2, 4, 4, 0, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb, fa, a3, 4, 4, 0, 0, 0, 0);
+      }
+    }
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += a0[i] + a1[i] + a2[i] + a3[i];
+    out[blockIdx.x * 256 + l] = s;
+  } else {
+    v16i a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+    v4i ia = {fa[0] & 0x01010101, fa[1] & 0x01010101, fa[2] & 0x01010101, fa[3] & 0x01010101};
+    v4i ib = {fb[0] & 0x01010101, fb[1] & 0x01010101, fb[2] & 0x01010101, fb[3] & 0x01010101};
+    for (int i = 0; i < iters; ++i) {
+      a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ia, ib, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ia, ib, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ib, ia, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ib, ia, a3, 0, 0, 0);
+    }
+    int s = 0;
+    for (int i = 0; i < 16; ++i) s += a0[i] + a1[i] + a2[i] + a3[i];
+    out[blockIdx.x * 256 + l] = (float)s;
+  }
+}
+
+int main() {
+  const uint32_t words = 64;  // 2048 samples
+  std::vector<uint32_t> A(32 * words), B(32 * words), want(32 * 32), have(32 * 32);
+  uint64_t s = 88172645463325252ull;
+  auto rnd = [&] {
+    s ^= s << 13;
+    s ^= s >> 7;
+    s ^= s << 17;
+    return (uint32_t)(s >> 16);
+  };
+  for (auto& x : A) x = rnd() & rnd();
+  for (auto& x : B) x = rnd() | (rnd() & rnd());
+  for (int r = 0; r < 32; ++r)
+    for (int c = 0; c < 32; ++c) {
+      uint32_t t = 0;
+      for (uint32_t w = 0; w < words; ++w) t += __builtin_popcount(A[r * words + w] & B[c * words + w]);
+      want[r * 32 + c] = t;
+    }
+  uint32_t *dA, *dB, *dC;
+  CHECK(hipMalloc(&dA, A.size() * 4));
+  CHECK(hipMalloc(&dB, B.size() * 4));
+  CHECK(hipMalloc(&dC, want.size() * 4));
+  CHECK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+  for (int mode = 0; mode < 2; ++mode) {
+    CHECK(hipMemset(dC, 0xff, want.size() * 4));
+    if (mode == 0) hipLaunchKernelGGL(count_fp4, dim3(1), dim3(64), 0, 0, dA, dB, words, dC);
+    else hipLaunchKernelGGL(count_i8, dim3(1), dim3(64), 0, 0, dA, dB, words, dC);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(have.data(), dC, have.size() * 4, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < 32 * 32; ++i) bad += have[i] != want[i];
+    std::printf("%s: %d of 1024 cells differ (cell[1][2]: have %u want %u)\n", mode == 0 ? "fp4" : "i8",
+                bad, have[1 * 32 + 2], want[1 * 32 + 2]);
+  }
+  // issue rate: 1024 workgroups of 4 waves (one per SIMD, four workgroups per CU)
+  float* dout;
+  CHECK(hipMalloc(&dout, 4096 * 256 * 4));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  const int iters = 20000;
+  for (int blocks : {256, 512, 1024}) {
+    for (int mode = 0; mode < 3; ++mode) {
+      for (int rep = 0; rep < 2; ++rep) {
+        CHECK(hipEventRecord(e0));
+        if (mode == 0) hipLaunchKernelGGL(rate_kernel<0>, dim3(blocks), dim3(256), 0, 0, dout, iters, 1u);
+        if (mode == 1) hipLaunchKernelGGL(rate_kernel<1>, dim3(blocks), dim3(256), 0, 0, dout, iters, 1u);
+        if (mode == 2) hipLaunchKernelGGL(rate_kernel<2>, dim3(blocks), dim3(256), 0, 0, dout, iters, 1u);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep == 1) {
+          const double mfma = (double)blocks * 4 * iters * 4;
+          const double per_simd_ns = ms * 1e6 / (mfma / 1024.0);
+          std::printf("%-10s blocks %4d: %.3f ms, %.2f ns per MFMA per SIMD (%.1f cycles at 2.4 GHz)\n",
+                      mode == 0 ? "fp4 scaled" : mode == 1 ? "i8" : "fp4 plain", blocks, ms, per_simd_ns,
+                      per_simd_ns * 2.4);
+        }
+      }
+    }
+  }
+  return 0;
+}
