@@ -534,26 +534,28 @@ __device__ __forceinline__ void mfma_tile_body(
   }
 }
 
+// A work unit of the matrix-core launch: one tile and a run of contraction
+// steps.  The host cuts every tile into runs of (nearly) equal cost -- steps x
+// column blocks -- so that all workgroups of a launch take the same time.
+struct MfmaUnit {
+  uint32_t row_tile, col_tile, step_lo, step_hi;
+};
+
 template <int KR, int KC>
 __global__ __launch_bounds__(256) void bitgemm_mfma_kernel(
     const uint32_t* __restrict__ planes, uint32_t wp, const RowDesc* __restrict__ rows,
     uint32_t nrows, const ColDesc* __restrict__ cols, uint32_t ncols_total,
-    const uint2* __restrict__ items, uint32_t nitems, uint32_t* __restrict__ counts,
-    uint32_t steps_total, uint32_t steps_per_split, int use_atomics) {
+    const MfmaUnit* __restrict__ units, uint32_t* __restrict__ counts, int use_atomics) {
   // two slabs of A and of B (one array: see bitgemm_kernel)
   __shared__ __attribute__((aligned(16))) uint32_t smem[2 * 2 * MFMA_TILE * LDS_STRIDE];
-  const uint32_t item_id = blockIdx.x % nitems;
-  const uint32_t split = blockIdx.x / nitems;
-  const uint2 it = items[item_id];
-  const uint32_t row0 = it.x * MFMA_TILE, col0 = it.y * MFMA_TILE;
+  const MfmaUnit u = units[blockIdx.x];
+  const uint32_t row0 = u.row_tile * MFMA_TILE, col0 = u.col_tile * MFMA_TILE;
   const uint32_t lim = rows[min(row0 + MFMA_TILE, nrows) - 1].ncols;  // the tile's last row has the most
   const uint32_t jm = (use_atomics & 2) ? 4u : lim > col0 ? min((lim - col0 + 31) / 32, 4u) : 1u;
-  const uint32_t step_lo = split * steps_per_split;
-  const uint32_t step_hi = min(step_lo + steps_per_split, steps_total);
   const bool atomics = (use_atomics & 1) != 0;
 #define OBNSL_MFMA_BODY(JM)                                                                       \
   mfma_tile_body<KR, KC, JM>(smem, planes, wp, rows, nrows, cols, ncols_total, row0, col0, counts, \
-                             step_lo, step_hi, atomics, (use_atomics & 4) != 0)
+                             u.step_lo, u.step_hi, atomics, (use_atomics & 4) != 0)
   switch (jm) {  // uniform over the workgroup
     case 1: OBNSL_MFMA_BODY(1); break;
     case 2: OBNSL_MFMA_BODY(2); break;
@@ -1350,6 +1352,11 @@ struct DevBuf {
 struct Batch {
   DevBuf<RowDesc> rows;
   DevBuf<uint2> items;
+  std::vector<uint2> h_items;          // host copy of `items` (tile coordinates), largest first
+  std::vector<uint32_t> h_item_blocks; // 32-column blocks of each item that hold a valid column
+  DevBuf<MfmaUnit> units;              // matrix-core launch: work units for `units_steps` steps
+  uint32_t nunits = 0, units_steps = 0, units_target = 0;
+  bool units_split = false;            // some tile is cut into several units (atomics needed)
   DevBuf<RowGroupDesc> rgs;
   uint32_t nrows = 0, nitems = 0, nrgs = 0;
   uint64_t ntables = 0, ncells = 0;
@@ -1701,6 +1708,9 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
                      });
     std::vector<uint2> items(tiles.size());
     for (size_t i = 0; i < tiles.size(); ++i) items[i] = tiles[i].second;
+    b->h_items = items;
+    b->h_item_blocks.resize(tiles.size());
+    for (size_t i = 0; i < tiles.size(); ++i) b->h_item_blocks[i] = (tiles[i].first + 31) / 32;
     b->nrows = (uint32_t)rows.size();
     b->nitems = (uint32_t)items.size();
     b->nrgs = (uint32_t)rgs.size();
@@ -1742,9 +1752,9 @@ template <int KR, int KC>
 void launch_bitgemm(obnsl_data* d, const Plan* p, const Batch* b, uint32_t* counts, uint32_t grid,
                     uint32_t steps_total, uint32_t steps_per_split, int atomics) {
   if (p->mfma)
-    hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC>), dim3(grid), dim3(256), 0, d->count_stream(),
+    hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC>), dim3(b->nunits), dim3(256), 0, d->count_stream(),
                        d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
-                       b->items.p, b->nitems, counts, steps_total, steps_per_split, atomics);
+                       b->units.p, counts, atomics);
   else if (p->tile == 128)
     hipLaunchKernelGGL((bitgemm_kernel<KR, KC, 8>), dim3(grid), dim3(256), 0, d->count_stream(),
                        d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
@@ -1755,8 +1765,50 @@ void launch_bitgemm(obnsl_data* d, const Plan* p, const Batch* b, uint32_t* coun
                        b->items.p, b->nitems, counts, steps_total, steps_per_split, atomics);
 }
 
+// Work units of the matrix-core launch of one batch: every tile is cut along the
+// contraction into runs whose cost (steps x column blocks) is close to
+// total cost / target, so a launch is `target` workgroups of equal length
+// (built once per batch and row count).
+obnsl_status build_units(Batch* b, uint32_t steps_total, uint32_t target) {
+  if (b->units_steps == steps_total && b->units_target == target && b->nunits) return OBNSL_OK;
+  uint64_t total = 0;
+  for (uint32_t blk : b->h_item_blocks) total += (uint64_t)blk * steps_total;
+  const double per_unit = std::max(1.0, (double)total / (double)std::max(1u, target));
+  std::vector<MfmaUnit> units;
+  std::vector<std::pair<uint32_t, MfmaUnit>> tmp;  // (cost, unit)
+  bool split = false;
+  for (size_t i = 0; i < b->h_items.size(); ++i) {
+    const uint32_t blk = b->h_item_blocks[i];
+    uint32_t ns = (uint32_t)std::max(1.0, std::floor((double)blk * steps_total / per_unit + 0.5));
+    ns = std::min(ns, std::max(1u, steps_total / 4));            // at least 4 steps per unit
+    ns = std::max(ns, (steps_total + MFMA_MAX_STEPS - 1) / MFMA_MAX_STEPS);  // f32 counts stay exact
+    ns = std::min(ns, steps_total);
+    if (ns > 1) split = true;
+    for (uint32_t sidx = 0; sidx < ns; ++sidx) {
+      MfmaUnit u;
+      u.row_tile = b->h_items[i].x;
+      u.col_tile = b->h_items[i].y;
+      u.step_lo = (uint32_t)((uint64_t)steps_total * sidx / ns);
+      u.step_hi = (uint32_t)((uint64_t)steps_total * (sidx + 1) / ns);
+      tmp.push_back({blk * (u.step_hi - u.step_lo), u});
+    }
+  }
+  std::stable_sort(tmp.begin(), tmp.end(),
+                   [](const std::pair<uint32_t, MfmaUnit>& x, const std::pair<uint32_t, MfmaUnit>& y) {
+                     return x.first > y.first;
+                   });
+  units.reserve(tmp.size());
+  for (auto& t : tmp) units.push_back(t.second);
+  HIP_TRY(b->units.upload(units));
+  b->nunits = (uint32_t)units.size();
+  b->units_steps = steps_total;
+  b->units_target = target;
+  b->units_split = split;
+  return OBNSL_OK;
+}
+
 // One bit-GEMM launch (timed with an event pair) filling `counts` for one batch.
-obnsl_status launch_count(obnsl_data* d, Plan* plan, const Batch* b, uint32_t* counts,
+obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
                           bool prezeroed = false) {
   if (b->nitems == 0) return OBNSL_OK;
   const uint32_t steps_total = d->wp / KCW;
@@ -1770,7 +1822,7 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, const Batch* b, uint32_t* c
   }();
   // the matrix-core kernel runs two 128 x 128 workgroups per CU: a few rounds of
   // 512 are enough, and every extra split adds the whole table in atomics
-  const uint32_t want = want_env ? want_env : plan->mfma ? 2048u : 8192u;
+  const uint32_t want = want_env ? want_env : plan->mfma ? 1024u : 8192u;
   static const uint32_t min_sps = [] {
     const char* e = std::getenv("OBNSL_MIN_SPS");
     return e ? std::max(1u, (uint32_t)std::atoi(e)) : 8u;
@@ -1781,7 +1833,11 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, const Batch* b, uint32_t* c
   if (plan->mfma) sps = std::min(sps, MFMA_MAX_STEPS);  // f32 accumulators stay exact below 2^24
   ksplit = (steps_total + sps - 1) / sps;
   static const int nojskip = (std::getenv("OBNSL_NO_JSKIP") ? 2 : 0) | (std::getenv("OBNSL_PROBE_NOLOAD") ? 4 : 0);
-  const int atomics = (ksplit > 1 ? 1 : 0) | nojskip;
+  if (plan->mfma) {
+    obnsl_status st = build_units(b, steps_total, std::max(want, b->nitems));
+    if (st != OBNSL_OK) return st;
+  }
+  const int atomics = ((plan->mfma ? b->units_split : ksplit > 1) ? 1 : 0) | nojskip;
   if ((atomics & 1) && !prezeroed)
     HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
   if (counts == plan->red.p) plan->wants_zero = (atomics & 1) != 0;
@@ -2104,7 +2160,6 @@ obnsl_status obnsl_data_create(const uint8_t* codes, uint64_t num_rows, uint64_t
   if (device < 0 || device >= ndev)
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "device index out of range");
   HIP_TRY(hipSetDevice(device));
-
   auto d = std::make_unique<obnsl_data>();
   d->device = device;
   d->N = num_rows;
@@ -2453,7 +2508,7 @@ obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_
       st = build_plan(d, kmax - 1, shard, num_shards, true, &part);
       if (st != OBNSL_OK) return st;
       const Batch* wb = full->batches[0].get();
-      const Batch* pb = part->batches[0].get();
+      Batch* pb = part->batches[0].get();
       if (part->slice_off + pb->ncells > wb->ncells)
         return fail(OBNSL_ERR_RUNTIME, "internal: slice outside the count table");
       if (full->zeroed_epoch != d->epoch)

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters, uint32
   }
 }
 
+int loop_main();
 int main() {
   const uint32_t words = 64;  // 2048 samples
   std::vector<uint32_t> A(32 * words), B(32 * words), want(32 * 32), have(32 * 32);
@@ -198,6 +199,103 @@ int main() {
         }
       }
     }
+  }
+  return loop_main();
+}
+
+// ---- inner-loop probe: the operand build + MFMA stream of the engine's tile loop,
+// fed from LDS, without global loads.  VAR 0: as the engine; 1: no operand build
+// (raw words as operands); 2: operands built once outside the loop (no LDS reads).
+typedef int pv8i __attribute__((ext_vector_type(8)));
+template <int J>
+__device__ __forceinline__ pv8i p_operand(const uint4 w) {
+  pv8i f;
+  if constexpr (J < 3) {
+    constexpr uint32_t m = 0x11111111u << J;
+    f[0] = (int)(w.x & m); f[1] = (int)(w.y & m); f[2] = (int)(w.z & m); f[3] = (int)(w.w & m);
+  } else {
+    f[0] = (int)((w.x >> 3) & 0x11111111u); f[1] = (int)((w.y >> 3) & 0x11111111u);
+    f[2] = (int)((w.z >> 3) & 0x11111111u); f[3] = (int)((w.w >> 3) & 0x11111111u);
+  }
+  f[4] = f[5] = f[6] = f[7] = 0;
+  return f;
+}
+__device__ __forceinline__ pv8i p_raw(const uint4 w) {
+  pv8i f = {(int)w.x, (int)w.y, (int)w.z, (int)w.w, 0, 0, 0, 0};
+  return f;
+}
+template <int VAR, int JM>
+__global__ __launch_bounds__(256) void loop_kernel(float* out, int steps) {
+  constexpr int STRIDE = 36;
+  __shared__ __attribute__((aligned(16))) uint32_t smem[2 * 2 * 128 * STRIDE];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 31, h4 = (lane >> 5) * 4;
+  for (uint32_t i = tid; i < 2 * 2 * 128 * STRIDE; i += 256) smem[i] = i * 2654435761u;
+  __syncthreads();
+  v16f acc[JM];
+  for (int j = 0; j < JM; ++j)
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0;
+  const uint32_t* sA = smem;
+  const uint32_t* sB = smem + 128 * STRIDE;
+  for (int s = 0; s < steps; ++s) {
+#pragma unroll 1
+    for (int rd = 0; rd < 4; ++rd) {
+      uint4 wa, wb[JM];
+      if (VAR != 2 || (s == 0 && rd == 0)) {
+        wa = *reinterpret_cast<const uint4*>(&sA[(wv * 32 + lr) * STRIDE + rd * 8 + h4]);
+#pragma unroll
+        for (int j = 0; j < JM; ++j) wb[j] = *reinterpret_cast<const uint4*>(&sB[(32 * j + lr) * STRIDE + rd * 8 + h4]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#define BLK(J, SC)                                                                                  \
+  {                                                                                                 \
+    const pv8i a = VAR == 0 ? p_operand<J>(wa) : p_raw(wa);                                         \
+    _Pragma("unroll") for (int j = 0; j < JM; ++j) acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4( \
+        a, VAR == 0 ? p_operand<J>(wb[j]) : p_raw(wb[j]), acc[j], 4, 4, 0, SC, 0, SC);              \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+  }
+      BLK(0, 0x80808080)
+      BLK(1, 0x7f7f7f7f)
+      BLK(2, 0x7e7e7e7e)
+      BLK(3, 0x80808080)
+#undef BLK
+    }
+  }
+  float sum = 0;
+  for (int j = 0; j < JM; ++j)
+    for (int i = 0; i < 16; ++i) sum += acc[j][i];
+  out[blockIdx.x * 256 + tid] = sum;
+}
+
+template <int VAR, int JM>
+void run_loop(float* dout, int blocks, const char* name) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  const int steps = 400;
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((loop_kernel<VAR, JM>), dim3(blocks), dim3(256), 0, 0, dout, steps);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep == 1) {
+      const double mfma_per_simd = (double)blocks * 4 * steps * 16 * JM / 1024.0;
+      std::printf("loop %-28s JM %d blocks %4d: %.3f ms, %.2f ns per MFMA per SIMD\n", name, JM, blocks, ms,
+                  ms * 1e6 / mfma_per_simd);
+    }
+  }
+}
+
+int loop_main() {
+  float* dout;
+  CHECK(hipMalloc(&dout, 4096 * 256 * 4));
+  for (int blocks : {256, 512}) {
+    run_loop<0, 4>(dout, blocks, "engine form");
+    run_loop<1, 4>(dout, blocks, "no operand build");
+    run_loop<2, 4>(dout, blocks, "no LDS reads, raw operands");
+    run_loop<0, 1>(dout, blocks, "engine form");
+    run_loop<0, 2>(dout, blocks, "engine form");
   }
   return 0;
 }
