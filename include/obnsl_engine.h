@@ -58,6 +58,7 @@ typedef enum {
 } obnsl_score_kind;
 
 #define OBNSL_MAX_SUBSET 8 /* largest subset size (max_parents + 1) the engine scores */
+#define OBNSL_NOALLOC_MAX_VARS 4096 /* variables obnsl_best_parents_device_noalloc serves */
 
 typedef struct obnsl_data obnsl_data; /* device-resident data set (opaque) */
 
@@ -183,6 +184,20 @@ obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
  * This is the record that ranks all-gather. */
 obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_scores,
                                        uint32_t max_parents, double* d_out);
+
+/* obnsl_best_parents_device for callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  Same inputs, same d_out, same
+ * kernels; the per-node arg-max words that obnsl_best_parents_device keeps in a
+ * buffer it allocates live here in a fixed array of the library's code object
+ * (2 * OBNSL_NOALLOC_MAX_VARS 8-byte words = 64 KiB per GPU, held until the
+ * process ends).  Calls hipMalloc / hipFree never; the kernels clear the words
+ * they use, with a fill kernel (no memset node).  A data set with more than
+ * OBNSL_NOALLOC_MAX_VARS variables -> OBNSL_ERR_UNSUPPORTED.  Every call on one
+ * GPU uses the same array: calls that overlap on one GPU (two streams, two
+ * handles) race -- serialise them. */
+obnsl_status obnsl_best_parents_device_noalloc(obnsl_data* d, const double* const* d_scores,
+                                               uint32_t max_parents, double* d_out);
 
 /* The combine step after ranks have all-gathered their obnsl_best_parents_device
  * records: d_parts (device) = `world` records of 3 * num_vars doubles, rank

@@ -33,12 +33,20 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
 
 #include "engine_internal.h"
 #include "obnsl_engine.h"
+
+// Scratch of obnsl_best_parents_device_noalloc: the per-node arg-max keys
+// [0, n) and ids [n, 2 n) that obnsl_best_parents_device keeps in memory it
+// allocates.  One copy per GPU, held until the process ends; every call on a
+// GPU shares it.  In host code the array's name is only a handle for
+// hipGetSymbolAddress: kernels and copies take the per-device address below.
+static __device__ __align__(256) unsigned long long scratch[2 * OBNSL_NOALLOC_MAX_VARS];
 
 namespace {
 
@@ -50,6 +58,10 @@ constexpr uint64_t BATCH_CELL_CAP = 1ull << 30;  // counters per batch (4 GiB)
 constexpr uint64_t REDUCED_MAX_CELLS = 4096;     // largest full table the reduced-mode scorer expands in LDS
 
 thread_local std::string g_err;
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+unsigned long long* g_scratch_ptr[MAX_DEVICES] = {nullptr};  // device address of `scratch`, per device
 
 obnsl_status fail(obnsl_status st, const std::string& msg) {
   g_err = msg;
@@ -2160,6 +2172,16 @@ obnsl_status obnsl_data_create(const uint8_t* codes, uint64_t num_rows, uint64_t
   if (device < 0 || device >= ndev)
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "device index out of range");
   HIP_TRY(hipSetDevice(device));
+  if (device < MAX_DEVICES) {
+    // once per device, with that device current: where this GPU holds `scratch`
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+      unsigned long long* ptr = nullptr;
+      HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+      g_scratch_ptr[device] = ptr;
+    }
+  }
+
   auto d = std::make_unique<obnsl_data>();
   d->device = device;
   d->N = num_rows;
@@ -2698,16 +2720,20 @@ obnsl_status obnsl_score_subsets(obnsl_data* d, obnsl_score_kind kind, double es
   return OBNSL_OK;
 }
 
+// `keys`: 2 n words of device memory, keys [0, n), ids [n, 2n); null = the data
+// set's own buffer (allocated on first use).
 static obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_scores,
-                                       uint32_t max_parents) {
+                                       uint32_t max_parents, unsigned long long* keys = nullptr) {
   if (max_parents + 1 > (uint32_t)KMAX || max_parents + 1 > d->n)
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   obnsl_status st = set_device(d->device);
   if (st != OBNSL_OK) return st;
-  DevBuf<unsigned long long>& buf = d->best_key;  // keys [0, n), ids [n, 2n)
-  HIP_TRY(buf.ensure(2 * (size_t)d->n));
-  unsigned long long* key = buf.p;
-  unsigned long long* id = buf.p + d->n;
+  if (!keys) {
+    HIP_TRY(d->best_key.ensure(2 * (size_t)d->n));
+    keys = d->best_key.p;
+  }
+  unsigned long long* key = keys;
+  unsigned long long* id = keys + d->n;
   hipLaunchKernelGGL(best_init_kernel, dim3((d->n + 255) / 256), dim3(256), 0, d->stream, key, id, d->n);
   BestArgs args;
   std::memset(&args, 0, sizeof(args));
@@ -2762,6 +2788,26 @@ obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_sco
   if (st != OBNSL_OK) return st;
   hipLaunchKernelGGL(best_decode_kernel, dim3((d->n + 255) / 256), dim3(256), 0, d->stream,
                      d->best_key.p, d->best_key.p + d->n, d->n, d_out);
+  HIP_TRY(hipGetLastError());
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_best_parents_device_noalloc(obnsl_data* d, const double* const* d_scores,
+                                               uint32_t max_parents, double* d_out) {
+  if (!d || !d_scores || !d_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (d->n > OBNSL_NOALLOC_MAX_VARS)
+    return fail(OBNSL_ERR_UNSUPPORTED,
+                "obnsl_best_parents_device_noalloc serves at most " +
+                    std::to_string(OBNSL_NOALLOC_MAX_VARS) + " variables (this data set has " +
+                    std::to_string(d->n) + "): use obnsl_best_parents_device");
+  unsigned long long* ptr = d->device < MAX_DEVICES ? g_scratch_ptr[d->device] : nullptr;
+  if (!ptr) return fail(OBNSL_ERR_RUNTIME, "no scratch address for this device");
+  // the arg-max kernels start from best_init_kernel's fill of [0, 2 n): what an
+  // earlier (possibly larger) call left in the array is never read
+  obnsl_status st = queue_best_parents(d, d_scores, max_parents, ptr);
+  if (st != OBNSL_OK) return st;
+  hipLaunchKernelGGL(best_decode_kernel, dim3((d->n + 255) / 256), dim3(256), 0, d->stream, ptr,
+                     ptr + d->n, d->n, d_out);
   HIP_TRY(hipGetLastError());
   return OBNSL_OK;
 }

@@ -55,6 +55,7 @@ SIGNATURES = {
     "obnsl_best_parents": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _f64p,
                                           _u32p, _u64p]),
     "obnsl_best_parents_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _vp]),
+    "obnsl_best_parents_device_noalloc": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _vp]),
     "obnsl_combine_best_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp]),
     "obnsl_exhaustive_search": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
                                                _u64p, _f64p]),
@@ -290,6 +291,11 @@ class Data:
         """Asynchronous; out_ptr: device pointer to 3 * n doubles (score, size, rank per node)."""
         arr = (_vp * len(score_ptrs))(*score_ptrs)
         _check(lib.obnsl_best_parents_device(self._h, arr, max_parents, out_ptr))
+
+    def best_parents_device_noalloc(self, score_ptrs, max_parents, out_ptr):
+        """best_parents_device without any device allocation (library-held scratch)."""
+        arr = (_vp * len(score_ptrs))(*score_ptrs)
+        _check(lib.obnsl_best_parents_device_noalloc(self._h, arr, max_parents, out_ptr))
 
     def combine_best_device(self, parts_ptr, world, out_ptr):
         """Asynchronous; parts_ptr: device pointer to world * 3 * n doubles (the all-gathered
