@@ -8,11 +8,16 @@ sets, and, with more than one GPU, all-gather those over RCCL.  The data matrix
 is resident in HBM before the timed region starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
-N > 1 is launched by torch.distributed.run, one rank per GPU.
+N > 1: one rank per GPU.  Started under torch.distributed.run the process is one
+rank (RANK / LOCAL_RANK / WORLD_SIZE from the environment); started plainly with
+--gpus N > 1 it starts the N ranks itself, as fresh child processes, before it
+has touched the GPU, and exits with their status.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,6 +41,8 @@ WORKLOADS = {
     "uniform20x8_1e6_bdeu_mp3": dict(gen="uniform20x8", N=1_000_000, max_parents=3, score="bdeu"),
 }
 HBM_PEAK_GBS = 8000.0
+# dense FP4 matrix-core peak: 1024 SIMDs x (32 x 32 x 64 multiply-adds per 32 cycles) x 2.4 GHz
+MFMA_FP4_PEAK_TFLOPS = 1024 * 32 * 32 * 64 * 2 / 32 * 2.4e9 / 1e12
 
 
 def make_data(spec):
@@ -53,17 +60,22 @@ def make_data(spec):
     raise ValueError(spec["gen"])
 
 
-def cpu_baseline(codes, card, names, max_parents, budget_s=20.0, data=None):
+def cpu_baseline(codes, card, names, max_parents, budget_s=20.0, timed_table=None):
     """Reference C++ (oracle/_ref) timed single-threaded, as the reference runs
-    it, on a bounded sample of size-(max_parents+1) subsets of this workload."""
+    it, on a bounded random sample of this workload's own size-(max_parents+1)
+    subsets (drawn over 16 randomly chosen columns, so that the string-typed
+    frame the reference ingests stays small).  timed_table: the host copy of the
+    score table of that size as the TIMED pass wrote it; the sampled subsets'
+    rows are compared with the reference's scores (the in-run parity gate)."""
     import oracle
-    from openbnsl_amd import synth
+    from openbnsl_amd import engine, synth
     k = max_parents + 1
     n = codes.shape[0]
     rng = np.random.default_rng(0)
-    ncols = min(n, 12)
+    ncols = min(n, 16)
     cols = sorted(rng.choice(n, size=ncols, replace=False).tolist())
     subs_all = oracle.enumerate_subsets(ncols, min(k, ncols))
+    subs_all = subs_all[rng.permutation(len(subs_all))]
     ref = oracle.ref()
     out = {}
     if ref is not None:
@@ -76,16 +88,17 @@ def cpu_baseline(codes, card, names, max_parents, budget_s=20.0, data=None):
         pick = [list(map(int, s)) for s in subs_all[:m]]
         secs, ref_scores = ref.score_subsets_timed(dfw, pick, 1.0)
         parity = None
-        if data is not None:
-            # the same tables from the engine (variable ids mapped back to the full matrix)
-            orig = np.array([[cols[i] for i in s] for s in pick], dtype=np.uint32)
-            have = data.score_subsets(orig)
+        if timed_table is not None and len(pick[0]) == k:
+            # rows of the table the timed pass wrote (variable ids mapped back to the full matrix)
+            ranks = [engine.rank([cols[i] for i in s]) for s in pick]
+            have = timed_table.reshape(-1, k)[ranks]
             want = np.array(ref_scores, dtype=np.float64)
             parity = float(np.max(np.abs(have - want) / np.abs(want)))
         out = {"value": m * len(pick[0]) / secs, "unit": "scores/s", "cores": 1, "kind": "reference",
                "parity_max_rel_err": parity, "parity_tables": m,
-               "sample": f"{m} size-{len(pick[0])} subsets over {ncols} of the {n} columns, all {codes.shape[1]} rows, "
-                         f"reference ContingencyTable + calculate_local_score, {secs:.1f} s"}
+               "parity_source": "rows of the score table written by the timed pass",
+               "sample": f"{m} random size-{len(pick[0])} subsets over {ncols} random columns of the {n}, "
+                         f"all {codes.shape[1]} rows, reference ContingencyTable + calculate_local_score, {secs:.1f} s"}
     else:
         sub_codes = np.ascontiguousarray(codes[cols[:6]])
         t0 = time.perf_counter()
@@ -104,6 +117,45 @@ def cpu_baseline(codes, card, names, max_parents, budget_s=20.0, data=None):
            "sample": f"{sc.shape[0]} size-{sc.shape[1]} subsets over {len(wide)} columns, all rows, "
                      f"oracle.c with OpenMP over subsets, {secs:.1f} s"}
     return out, omp
+
+
+def stream_read_gbs(torch, engine, dev, nbytes=2 << 30, reps=5):
+    """Read bandwidth the memory system gives a plain streaming kernel (16 bytes
+    per lane) over a buffer far larger than the 256 MiB Infinity Cache."""
+    buf = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+    buf.random_(0, 1 << 20)
+    sink = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    engine.stream_read(buf.data_ptr(), nbytes, stream, sink.data_ptr())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        engine.stream_read(buf.data_ptr(), nbytes, stream, sink.data_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def spawn_ranks(n):
+    """Starts this script once per rank (fresh processes; this parent has not
+    touched the GPU and never does), waits for them, returns the worst status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    for pr in procs:
+        rc = pr.wait()
+        if rc != 0:
+            worst = worst or rc
+            for other in procs:        # a dead rank leaves the others waiting in a collective
+                if other.poll() is None:
+                    other.terminate()
+    return worst
 
 
 def exhaustive_search_wallclock(engine, with_cpu):
@@ -189,6 +241,9 @@ def main():
                          "(profiling runs: every kernel launch then belongs to the timed pass)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     from openbnsl_amd import engine
@@ -198,7 +253,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # rehearsal on a box with fewer GPUs than ranks: OBNSL_BENCH_BACKEND=gloo maps
     # every rank to an existing device and exchanges through host memory
     backend = os.environ.get("OBNSL_BENCH_BACKEND", "nccl")
@@ -218,6 +273,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != world:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
 
     spec = WORKLOADS[args.workload]
     codes, card, names = make_data(spec)
@@ -254,40 +311,66 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_scores * args.steps / elapsed
+    # host copy of the top-size score table exactly as the timed pass left it (the
+    # parity gate of the cpu_baseline leg reads its rows)
+    timed_top = tables[mp].detach().cpu() if (rank == 0 and world == 1) else None
 
-    # dominant kernel: the bit-GEMM of the largest subset size.  Algorithmic
-    # bytes of one launch = N bytes per score x the scores that launch yields
-    # (one uint8 column of N rows read per (child, parent set) score).
+    # dominant kernel: the counting launch of the largest subset size, timed live
+    # with HIP events on the stream it runs on (obnsl_kernel_time).
     k_top = mp + 1
     total_ms, launches = data.kernel_time(k_top)
     launches_per_step = max(1, launches // max(1, args.steps))
     kernel_ms = total_ms / max(1, launches)       # average duration of one launch
+    path = data.count_path(k_top)
     # scores of this rank's shard of the top size (count the finite entries)
+    top_scores_all = data.num_subsets(k_top) * k_top
     top_scores_rank = int(torch.isfinite(tables[k_top - 1]).sum().item())
+    # SURVEY's algorithmic bytes: N bytes per (child, parent set) score (one uint8
+    # column of N rows per score) x the scores one launch yields
     alg_bytes_per_launch = top_scores_rank * N / launches_per_step
-    achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+    hbm_alg = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
 
-    # HBM traffic of that kernel: not measurable from inside this process (PMC
-    # counters need a rocprofv3 pass); taken from the committed pass over this
-    # same command when the workload matches, else null
-    traffic, traffic_src, valu = None, None, None
+    # HBM traffic of that kernel: PMC counters need rocprofv3 passes of their own
+    # (tools/profile_bench.sh); the committed summary is quoted only when it was
+    # taken on this workload with this kernel, else null
+    traffic, traffic_src = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc_path) and world == 1:
         with open(pmc_path) as f:
             pmc = json.load(f)
-        if pmc.get("workload") == args.workload:
+        if pmc.get("workload") == args.workload and pmc.get("count_path") == path:
             traffic = pmc["traffic_bytes_per_launch"] / 1e9
-            traffic_src = "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, GB per launch)"
-            instr = pmc.get("instructions_per_launch", {}).get("SQ_INSTS_VALU")
-            if instr and kernel_ms > 0:
-                # what actually bounds the kernel: vector-ALU issue.  Its instruction stream is
-                # and/popcount pairs, 2 + 4 cycles per wave64 pair per SIMD (measured issue costs,
-                # profiles/r1h_ubench_valu.txt); peak = 1024 SIMDs at the 2.4 GHz maximum clock.
-                peak = 1024 * 2.4e9 / 3.0
-                valu = {"bound": "valu-issue", "wave_instructions_per_launch": instr,
-                        "achieved": instr / (kernel_ms * 1e-3), "peak": peak,
-                        "unit": "wave64 instructions/s", "frac": instr / (kernel_ms * 1e-3) / peak,
-                        "source": "SQ_INSTS_VALU from profiles/pmc_summary.json; live kernel time"}
+            traffic_src = ("profiles/pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                           "passes over this command, GB per launch, FETCH_SIZE doubled as on gfx950)")
+
+    if path == "mfma" and kernel_ms > 0:
+        # what binds the launch: the matrix cores.  Algorithmic work = one
+        # multiply-add per (counted cell, sample): the cells are the joint states
+        # with every variable in a non-reference state (the others follow by
+        # inclusion-exclusion in the scorer), each FP4 multiply-add is one AND of
+        # two sample bits.  Peak = dense FP4 rate of the chip.
+        try:
+            cells = data.counts_cells(k_top) * (top_scores_rank / top_scores_all)
+        except Exception:  # noqa: BLE001
+            cells = None
+        flops = 2.0 * cells * N / launches_per_step if cells else None
+        ach = flops / (kernel_ms * 1e-3) / 1e12 if flops else None
+        roofline = {"bound": "mfma", "achieved": ach, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_FP4_PEAK_TFLOPS if ach else None, "traffic": traffic,
+                    "traffic_unit": "GB per launch", "traffic_source": traffic_src,
+                    "kernel": f"bitgemm_mfma_kernel (subset size {k_top}, FP4 32x32x64)",
+                    "kernel_ms": kernel_ms, "launches_per_step": launches_per_step,
+                    "algorithmic_flops_per_launch": flops,
+                    "algorithmic_cells_per_launch": cells,
+                    "note": "2 flops per (counted cell, sample); peak = 1024 SIMDs x 65536 FP4 "
+                            "multiply-adds per 32 cycles at 2.4 GHz"}
+    else:
+        roofline = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (hbm_alg / HBM_PEAK_GBS) if hbm_alg else None, "traffic": traffic,
+                    "traffic_unit": "GB per launch", "traffic_source": traffic_src,
+                    "kernel": f"counting kernel of subset size {k_top} ({path} path)",
+                    "kernel_ms": kernel_ms, "launches_per_step": launches_per_step,
+                    "algorithmic_bytes_per_launch": alg_bytes_per_launch}
 
     out = {
         "metric": "parent-set scores/sec",
@@ -300,27 +383,31 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "u32 popcount counts + f64 lgamma",
+        "dtype": "fp4 0/1 multiply-adds with exact f32 counts (u32 tables) + f64 lgamma"
+                 if path == "mfma" else "u32 counts + f64 lgamma",
         "data": "synthetic",
         "config": {"workload": args.workload, "num_vars": int(n), "num_rows": int(N),
                    "max_parents": mp, "score": spec["score"], "scores_per_step": int(n_scores),
+                   "world_size": int(dist.get_world_size()) if exchange else 1,
+                   "backend": (dist.get_backend() if exchange else None),
                    "sharding": f"subsets split over {world} rank(s) by cost; per-node bests all-gathered"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                     "traffic_unit": "GB per launch (compare with algorithmic_bytes_per_launch)",
-                     "traffic_source": traffic_src,
-                     "kernel": f"bitgemm_kernel (subset size {k_top})",
-                     "kernel_ms": kernel_ms, "launches_per_step": launches_per_step,
-                     "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+        "roofline": roofline,
+        # the survey's fixed definition, kept beside the binding roofline: algorithmic
+        # column bytes per second against the HBM peak (the row bitmaps are cache
+        # resident and 8x denser than the columns, so this exceeds 1 by design)
+        "roofline_hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": (hbm_alg / HBM_PEAK_GBS) if hbm_alg else None,
+                                     "algorithmic_bytes_per_launch": alg_bytes_per_launch},
     }
-    if valu:
-        out["roofline_valu"] = valu
+    if rank == 0 and world == 1 and not args.only_hot_path:
+        out["hbm_stream_read_gbs"] = stream_read_gbs(torch, engine, dev)
     if rank == 0 and world == 1 and not args.only_hot_path:
         out["exhaustive_search"] = exhaustive_search_wallclock(engine, not args.no_cpu_baseline)
         out["simulated_annealing"] = simulated_annealing_wallclock(engine, data, not args.no_cpu_baseline)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.only_hot_path:
         try:
-            base, omp = cpu_baseline(codes, card, names, mp, data=data)
+            base, omp = cpu_baseline(codes, card, names, mp,
+                                     timed_table=timed_top.numpy() if timed_top is not None else None)
             out["cpu_baseline"] = base
             out["cpu_baseline_omp"] = omp
         except Exception as e:  # noqa: BLE001

@@ -282,6 +282,23 @@ uint64_t obnsl_rank(const uint32_t* var_ids, uint32_t k);
 obnsl_status obnsl_kernel_time(obnsl_data* d, uint32_t k, double* total_ms, uint32_t* launches,
                                int reset);
 
+/* Which kernel counts the tables of subset size k on this data set (no
+ * counterpart in the reference, whose one loop is contingency_table.h:52-55):
+ * the bit-plane contraction on the matrix cores, the same on the vector ALU
+ * (OBNSL_GEMM=valu), or the per-row histogram for tables with many cells. */
+#define OBNSL_PATH_MFMA 0
+#define OBNSL_PATH_VALU 1
+#define OBNSL_PATH_HISTOGRAM 2
+obnsl_status obnsl_count_path(obnsl_data* d, uint32_t k, int* path_out);
+
+/* Calibration helper with no counterpart in the reference: one plain streaming
+ * read (16 bytes per lane) of `bytes` bytes of device memory at d_src (16-byte
+ * aligned), queued on hip_stream; d_sink is one device word the kernel may
+ * write.  The caller times it (events on that stream) to obtain the read
+ * bandwidth the memory system delivers to a kernel that does nothing else --
+ * the achievable figure quoted beside the nominal HBM peak. */
+obnsl_status obnsl_stream_read(const void* d_src, uint64_t bytes, void* hip_stream, uint32_t* d_sink);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,6 +174,27 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(
   if (bad_code && (covered & valid) != valid) *bad_code = v + 1;
 }
 
+// ------------------------------------------------------------------ calibration
+// Plain streaming read, 16 bytes per lane, grid-stride: what the memory system
+// delivers to a kernel that does nothing else (the achievable figure beside the
+// nominal 8 TB/s when a roofline fraction is quoted).  The XOR of everything
+// read goes to `sink` so the loads cannot be dropped.
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restrict__ src, uint64_t n16,
+                                                          uint32_t* __restrict__ sink) {
+  uint32_t acc = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {  // four loads in flight per lane
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], e = src[i + 3 * stride];
+    acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ e.x ^ e.y ^ e.z ^ e.w;
+  }
+  for (; i < n16; i += stride) {
+    const uint4 a = src[i];
+    acc ^= a.x ^ a.y ^ a.z ^ a.w;
+  }
+  if (acc == 0x9e3779b9u) sink[0] = acc;  // practically never: keeps the loads alive
+}
+
 // ------------------------------------------------------------------ bit-GEMM
 __device__ __forceinline__ uint4 and4(uint4 a, uint4 b) {
   return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w);
@@ -2888,6 +2909,28 @@ obnsl_status obnsl_exhaustive_search(obnsl_data* d, obnsl_score_kind kind, doubl
   HIP_TRY(hipMemcpyAsync(&tot, total.p, sizeof(double), hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
   if (total_score_out) *total_score_out = tot;
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_count_path(obnsl_data* d, uint32_t k, int* path_out) {
+  if (!d || !path_out || k == 0 || k > (uint32_t)KMAX || k > d->n)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "bad obnsl_count_path arguments");
+  obnsl_status st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  bool red = false;
+  st = choose_reduced(d, k, &red, nullptr);
+  if (st != OBNSL_OK) return st;
+  *path_out = !red ? OBNSL_PATH_HISTOGRAM : use_mfma_gemm() ? OBNSL_PATH_MFMA : OBNSL_PATH_VALU;
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_stream_read(const void* d_src, uint64_t bytes, void* hip_stream, uint32_t* d_sink) {
+  if (!d_src || !d_sink || bytes < 16 || (reinterpret_cast<uintptr_t>(d_src) & 15))
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "obnsl_stream_read needs a 16-byte aligned buffer of at least 16 bytes");
+  hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 16), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(hip_stream), static_cast<const uint4*>(d_src),
+                     bytes / 16, d_sink);
+  HIP_TRY(hipGetLastError());
   return OBNSL_OK;
 }
 

@@ -76,6 +76,8 @@ SIGNATURES = {
     "obnsl_binomial": (ctypes.c_uint64, [ctypes.c_uint32, ctypes.c_uint32]),
     "obnsl_unrank": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, _u32p]),
     "obnsl_rank": (ctypes.c_uint64, [_u32p, ctypes.c_uint32]),
+    "obnsl_count_path": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int)]),
+    "obnsl_stream_read": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, _vp]),
     "obnsl_kernel_time": (ctypes.c_int, [_vp, ctypes.c_uint32, _f64p, _u32p, ctypes.c_int]),
 }
 
@@ -104,6 +106,11 @@ def device_count():
     c = ctypes.c_int(0)
     _check(lib.obnsl_device_count(ctypes.byref(c)))
     return c.value
+
+
+def stream_read(src_ptr, nbytes, stream_handle, sink_ptr):
+    """Queues one plain streaming read of device memory (calibration; the caller times it)."""
+    _check(lib.obnsl_stream_read(src_ptr, nbytes, stream_handle, sink_ptr))
 
 
 def binomial(n, k):
@@ -323,6 +330,12 @@ class Data:
                                              par.ctypes.data_as(_u32p), cnt.ctypes.data_as(_u32p),
                                              ctypes.byref(total)))
         return [par[v, :cnt[v]].tolist() for v in range(self.n)], total.value
+
+    def count_path(self, k):
+        """"mfma", "valu" or "histogram": the kernel that counts the size-k tables."""
+        path = ctypes.c_int(-1)
+        _check(lib.obnsl_count_path(self._h, k, ctypes.byref(path)))
+        return {0: "mfma", 1: "valu", 2: "histogram"}[path.value]
 
     def kernel_time(self, k, reset=False):
         """(total ms, launches) of the size-k counting kernel since the last reset."""
