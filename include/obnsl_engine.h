@@ -156,6 +156,18 @@ obnsl_status obnsl_counts_mark_summed(obnsl_data* d, uint32_t k);
 obnsl_status obnsl_counts_export(obnsl_data* d, uint32_t k, uint32_t* d_dst);
 obnsl_status obnsl_counts_import(obnsl_data* d, uint32_t k, const uint32_t* d_src);
 
+/* Inspection of what the batch counting kernel produced (no counterpart in the
+ * reference, which keeps one table at a time, contingency_table.h:24-27): the
+ * slice of the resident size-k count table that belongs to the subset var_ids
+ * (ascending) -- the counts of the joint states in which EVERY variable is in
+ * one of its states 1..r-1, prod(r_v - 1) words, first variable most
+ * significant (state s of a variable is digit s - 1).  The full table follows
+ * from these slices of all sub-subsets by inclusion-exclusion (what the scorer
+ * does).  Counts the size first if the current row bitmaps have not been
+ * counted yet.  OBNSL_ERR_UNSUPPORTED for a size served by the per-row path. */
+obnsl_status obnsl_reduced_table(obnsl_data* d, const uint32_t* var_ids, uint32_t k,
+                                 uint32_t* table_out, uint64_t capacity);
+
 /* Number of size-k subsets, C(num_vars, k), and of scores, k * C(num_vars, k). */
 obnsl_status obnsl_num_subsets(const obnsl_data* d, uint32_t k, uint64_t* num_subsets);
 

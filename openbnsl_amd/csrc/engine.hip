@@ -1414,6 +1414,8 @@ struct Plan {
   // reduced mode: the counters persist per plan, so that larger subsets can read them
   DevBuf<uint32_t> red;
   DevBuf<uint64_t> rowoff;      // by colex rank of the kr-subset
+  std::vector<uint64_t> h_rowoff;       // host copies (obnsl_reduced_table)
+  std::vector<uint32_t> h_col_before;   // by colex rank of the kc-subset
   uint64_t counted_epoch = 0;   // data epoch the counters in `red` belong to
   int pending_lane = -1;        // side lane still producing `red` (-1: none, or already joined)
   uint64_t zeroed_epoch = 0;    // data epoch at whose pack `red` was cleared
@@ -1756,6 +1758,9 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     plan->batches.push_back(std::move(b));
   }
   if (reduced) {
+    plan->h_rowoff = rowoff;
+    plan->h_col_before.resize(cgs.size());
+    for (size_t g2 = 0; g2 < cgs.size(); ++g2) plan->h_col_before[g2] = cgs[g2].col_before;
     HIP_TRY(plan->rowoff.upload(rowoff));
     HIP_TRY(plan->red.ensure(std::max<uint64_t>(plan->batches[0]->ncells, 1)));
   }
@@ -2645,6 +2650,49 @@ obnsl_status obnsl_counts_mark_summed(obnsl_data* d, uint32_t k) {
   obnsl_status st = whole_table(d, k, &p);
   if (st != OBNSL_OK) return st;
   p->awaits_sum = false;
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_reduced_table(obnsl_data* d, const uint32_t* var_ids, uint32_t k,
+                                 uint32_t* table_out, uint64_t capacity) {
+  if (!d || !var_ids || !table_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (k == 0 || k > (uint32_t)KMAX || k > d->n)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "subset size must be in [1, min(num_vars, OBNSL_MAX_SUBSET)]");
+  for (uint32_t i = 0; i < k; ++i) {
+    if (var_ids[i] >= d->n) return fail(OBNSL_ERR_OUT_OF_RANGE, "variable id out of range");
+    if (i && var_ids[i] <= var_ids[i - 1])
+      return fail(OBNSL_ERR_INVALID_ARGUMENT, "var_ids must be sorted");
+  }
+  obnsl_status st = set_device(d->device);
+  if (st != OBNSL_OK) return st;
+  bool red = false;
+  st = choose_reduced(d, k, &red, nullptr);
+  if (st != OBNSL_OK) return st;
+  if (!red)
+    return fail(OBNSL_ERR_UNSUPPORTED, "tables of this subset size are counted per row, not by the bit-plane contraction");
+  Plan* p = nullptr;
+  st = build_plan(d, k, 0, 1, true, &p);
+  if (st != OBNSL_OK) return st;
+  st = ensure_counts(d, p);
+  if (st != OBNSL_OK) return st;
+  // the kc smallest variables are the column side, the others the row side
+  uint64_t colrank = 0, rowrank = 0, M = 1, cells = 1;
+  for (uint32_t j = 0; j < p->kc; ++j) {
+    colrank += binom_host(var_ids[j], j + 1);
+    cells *= d->card[var_ids[j]] - 1;
+  }
+  for (uint32_t j = 0; j < p->kr; ++j) {
+    rowrank += binom_host(var_ids[p->kc + j], j + 1);
+    M *= d->card[var_ids[p->kc + j]] - 1;
+  }
+  cells *= M;
+  if (cells > capacity) return fail(OBNSL_ERR_INVALID_ARGUMENT, "table_out is too small");
+  const uint64_t col_before = p->kc ? p->h_col_before[colrank] : 0;
+  const uint64_t base = p->h_rowoff[rowrank] + col_before * M;
+  if (cells)
+    HIP_TRY(hipMemcpyAsync(table_out, p->red.p + base, cells * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
   return OBNSL_OK;
 }
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "obnsl_counts_mark_summed": (ctypes.c_int, [_vp, ctypes.c_uint32]),
     "obnsl_counts_export": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
     "obnsl_counts_import": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
+    "obnsl_reduced_table": (ctypes.c_int, [_vp, _u32p, ctypes.c_uint32, _u32p, ctypes.c_uint64]),
     "obnsl_num_subsets": (ctypes.c_int, [_vp, ctypes.c_uint32, _u64p]),
     "obnsl_score_subsets": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, _u32p,
                                            ctypes.c_uint32, ctypes.c_uint64, _f64p]),
@@ -250,6 +251,41 @@ class Data:
 
     def counts_import(self, k, src_ptr):
         _check(lib.obnsl_counts_import(self._h, k, src_ptr))
+
+    def reduced_table(self, var_ids):
+        """The batch kernel's own counts of the subset: uint32 array shaped (r_v - 1 ...),
+        entry [s_1 - 1, ..., s_k - 1] = rows with every variable v_i in state s_i >= 1."""
+        v = np.ascontiguousarray(var_ids, dtype=np.uint32)
+        shape = tuple(int(self.card[int(i)]) - 1 for i in v)
+        out = np.zeros(max(int(np.prod(shape, dtype=np.int64)), 1), dtype=np.uint32)
+        _check(lib.obnsl_reduced_table(self._h, v.ctypes.data_as(_u32p), len(v),
+                                       out.ctypes.data_as(_u32p), len(out)))
+        return out[:int(np.prod(shape, dtype=np.int64))].reshape(shape)
+
+    def full_table_from_reduced(self, var_ids):
+        """The dense table of the subset (keyed as count()) rebuilt on the host from the
+        batch kernel's reduced tables of all its sub-subsets, by inclusion-exclusion."""
+        import itertools
+        v = [int(i) for i in var_ids]
+        k = len(v)
+        cards = [int(self.card[i]) for i in v]
+        # E[e_1..e_k]: digit 0 = "any state", digit s >= 1 = state s
+        E = np.zeros(cards, dtype=np.int64)
+        E[(0,) * k] = self.N
+        for size in range(1, k + 1):
+            for pos in itertools.combinations(range(k), size):
+                red = self.reduced_table([v[i] for i in pos]).astype(np.int64)
+                idx = [0] * k
+                for i in pos:
+                    idx[i] = slice(1, None)
+                E[tuple(idx)] = red
+        for axis in range(k):        # "any" -> state 0, one variable at a time
+            idx0 = [slice(None)] * k
+            idx0[axis] = 0
+            rest = [slice(None)] * k
+            rest[axis] = slice(1, None)
+            E[tuple(idx0)] -= E[tuple(rest)].sum(axis=axis)
+        return E.reshape(-1).astype(np.uint64)
 
     def num_subsets(self, k):
         return binomial(self.n, k)

@@ -91,3 +91,61 @@ def test_large_tile_instances_still_count_exactly():
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "smoke ok" in out.stdout
+
+
+def _full_size_worker(rank, world, port, q, workload):
+    """One rank of a benchmark workload at its own size (ranks share the one GPU,
+    gloo on host copies): the sharded pass twice, then rank 0 runs the same pass
+    unsharded and compares the combined per-node best parent sets."""
+    import torch
+    import torch.distributed as dist
+    import bench
+    from openbnsl_amd import engine
+    from openbnsl_amd.pipeline import HotPath
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = bench.WORKLOADS[workload]
+    codes, card, _ = bench.make_data(spec)
+    kind = engine.BDEU if spec["score"] == "bdeu" else engine.BIC
+    mp = spec["max_parents"]
+    hot = HotPath(codes, card, mp, kind=kind, rank=rank, world=world, device_index=0)
+    best = None
+    for _ in range(2):
+        best = hot.step()
+    torch.cuda.synchronize()
+    got = HotPath.to_host(best)
+    covered = torch.tensor([sum(hot.shard_scores(k) for k in range(1, mp + 2))], dtype=torch.int64)
+    dist.all_reduce(covered)
+    hot.close()
+    ok = True
+    if rank == 0:
+        one = HotPath(codes, card, mp, kind=kind, rank=0, world=1, device_index=0)
+        want = HotPath.to_host(one.step())
+        torch.cuda.synchronize()
+        ok = all((a == b).all() for a, b in zip(got, want)) and int(covered.item()) == one.scores_per_pass
+        one.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("workload,world", [("alarm37_1e6_bdeu_mp3", 2), ("alarm37_1e6_bdeu_mp3", 8),
+                                            ("alarm37_1e6_bic_mp4", 4)])
+def test_benchmark_workload_sharded_equals_unsharded(workload, world):
+    """Every score covered exactly once over the ranks; combined best parent sets
+    identical (scores bit for bit, sizes, ranks) to the unsharded pass."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_full_size_worker, args=(r, world, port, q, workload)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=400) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(world)]
