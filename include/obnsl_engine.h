@@ -57,7 +57,12 @@ typedef enum {
   OBNSL_SCORE_AIC = 3
 } obnsl_score_kind;
 
-#define OBNSL_MAX_SUBSET 8 /* largest subset size (max_parents + 1) the engine scores */
+/* Largest subset size (max_parents + 1) the engine counts and scores.  The
+ * reference has no such bound (contingency_table.h:34-56 takes any var_ids); a
+ * table here is dense, so it also has to stay within 2^26 cells.  Sizes up to 8
+ * go through the bit-plane contraction, larger ones through the per-row
+ * histogram kernel. */
+#define OBNSL_MAX_SUBSET 32
 #define OBNSL_NOALLOC_MAX_VARS 4096 /* variables obnsl_best_parents_device_noalloc serves */
 
 typedef struct obnsl_data obnsl_data; /* device-resident data set (opaque) */

@@ -50,7 +50,8 @@ static __device__ __align__(256) unsigned long long scratch[2 * OBNSL_NOALLOC_MA
 
 namespace {
 
-constexpr int KMAX = OBNSL_MAX_SUBSET;  // largest subset size
+constexpr int KMAX = OBNSL_MAX_SUBSET;  // largest subset size (per-row counting path)
+constexpr int KFAST = 8;                // largest subset size of the bit-plane contraction (2 KSIDE)
 constexpr int KSIDE = 4;                // largest kr / kc
 constexpr int KCW = 32;                 // 32-bit words of the contraction per LDS slab
 constexpr int LDS_STRIDE = KCW + 4;     // padded slab row (words): conflict-free b128 reads
@@ -602,6 +603,7 @@ __global__ __launch_bounds__(256) void bitgemm_mfma_kernel(
 // Dense counts of one explicit subset: counts[cell] += popc(AND of the cell's
 // planes) over this block's share of the words.  Generic and simple: it serves
 // the one-table calls (ContingencyTable(var_ids, df)), not the batch path.
+template <int KCAP>
 __global__ __launch_bounds__(256) void count_single_kernel(
     const uint32_t* __restrict__ planes, uint32_t wp, uint32_t k, const uint32_t* __restrict__ pbase,
     const uint32_t* __restrict__ cards, uint32_t cells, uint32_t* __restrict__ counts,
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(256) void count_single_kernel(
   __shared__ uint32_t red[4];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t cell = blockIdx.y; cell < cells; cell += gridDim.y) {
-    uint32_t pl[KMAX];
+    uint32_t pl[KCAP];
     uint32_t rem = cell;
     for (int j = (int)k - 1; j >= 0; --j) {
       pl[j] = pbase[j] + rem % cards[j];
@@ -637,6 +639,7 @@ __global__ __launch_bounds__(256) void count_single_kernel(
 // strides over its cells, blockIdx.z over chunks of the rows.  The row chunk is
 // the slowest grid dimension: the workgroups in flight together read the same
 // words of (different) planes, a working set that stays in L2.
+template <int KCAP>
 __global__ __launch_bounds__(256) void count_list_kernel(
     const uint32_t* __restrict__ planes, uint32_t wp, uint32_t k,
     const uint32_t* __restrict__ pbase_all, const TableDesc* __restrict__ tds,
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(256) void count_list_kernel(
   uint32_t* __restrict__ dst = counts + tds[t].off;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t cell = blockIdx.y; cell < cells; cell += gridDim.y) {
-    uint32_t pl[KMAX];
+    uint32_t pl[KCAP];
     uint32_t rem = cell;
     for (int j = (int)k - 1; j >= 0; --j) {
       pl[j] = pbase[j] + rem % cards[j];
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(256) void score_plan_kernel(
   }
   const RowGroupDesc rg = rgs[lo];
   const uint32_t gamma = (uint32_t)(t - rg.tbl_start);
-  uint32_t cards[KMAX];
+  uint32_t cards[KFAST];
   uint32_t col_before = 0;
   if (kc > 0) {
     const ColGroupDesc cg = cgs[gamma];
@@ -830,7 +833,7 @@ struct SizeView {            // where the reduced tables of one subset size live
   uint32_t kr, kc;
 };
 struct ReducedViews {
-  SizeView v[KMAX + 1];
+  SizeView v[KFAST + 1];
 };
 
 // One wavefront (one 64-thread workgroup) per table: gather E from the reduced
@@ -860,15 +863,15 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
   // that latency than one.  Both halves pass the same barriers; a half without a
   // table (odd count) idles through them.
   extern __shared__ __attribute__((aligned(16))) uint32_t E_all[];
-  __shared__ SizeView sv[KMAX + 1];
-  __shared__ uint32_t s_vars[2][KMAX], s_cards[2][KMAX];
+  __shared__ SizeView sv[KFAST + 1];
+  __shared__ uint32_t s_vars[2][KFAST], s_cards[2][KFAST];
   __shared__ uint64_t pat_base_all[2][1 << KT];  // first counter of the reduced table of a support pattern
   constexpr uint32_t k = KT;
   const uint32_t half = threadIdx.x >> 5, lane = threadIdx.x & 31;
   uint32_t* E = E_all + (size_t)half * e_stride;
   uint64_t* pat_base = pat_base_all[half];
 #pragma unroll
-  for (int j = 0; j <= KMAX; ++j)
+  for (int j = 0; j <= KFAST; ++j)
     if (threadIdx.x == (uint32_t)j) sv[j] = views.v[j];
   const uint64_t t0 = (uint64_t)blockIdx.x * tables_per_wg;
   const uint64_t t1 = min(t0 + (uint64_t)tables_per_wg, ntables);
@@ -888,11 +891,11 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
   for (uint64_t tp = t0; tp < t1; tp += 2) {
     const uint64_t t = tp + half;
     const bool active = t < t1;
-    uint32_t vars[KMAX], cards[KMAX];
-    float inv_card[KMAX];
+    uint32_t vars[KFAST], cards[KFAST];
+    float inv_card[KFAST];
     uint32_t cells = 1, gamma = 0;
 #pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
+    for (int i = 0; i < KFAST; ++i) {
       vars[i] = 0;
       cards[i] = 1;
       inv_card[i] = 1.0f;
@@ -904,14 +907,14 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
       ColGroupDesc cg;
       if (kc > 0) cg = own_cgs[gamma];
 #pragma unroll
-      for (int i = 0; i < KMAX; ++i) {
+      for (int i = 0; i < KFAST; ++i) {
         if (i < KSIDE && i < (int)kc) vars[i] = cg.vars[i];
 #pragma unroll
         for (int j = 0; j < KSIDE; ++j)
           if (i == (int)kc + j && j < (int)kr) vars[i] = rg.vars[j];
       }
 #pragma unroll
-      for (int i = 0; i < KMAX; ++i) {
+      for (int i = 0; i < KFAST; ++i) {
         if (i < (int)k) {
           cards[i] = card[vars[i]];
           inv_card[i] = 1.0f / (float)cards[i];
@@ -925,7 +928,7 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
         uint64_t colrank = 0, rowrank = 0;
         uint32_t mred = 1, p = 0;
 #pragma unroll
-        for (int i = 0; i < KMAX; ++i) {
+        for (int i = 0; i < KFAST; ++i) {
           if (i >= (int)k || !(pat >> i & 1)) continue;
           ++p;
           if (p <= s.kc) {
@@ -946,7 +949,7 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
       for (uint32_t cell = lane; cell < cells; cell += 32) {
         uint32_t rem = cell, pat = 0, key = 0, mul = 1;
 #pragma unroll
-        for (int i = KMAX - 1; i >= 0; --i) {
+        for (int i = KFAST - 1; i >= 0; --i) {
           if (i >= (int)k) continue;
           const uint32_t qt = fast_div(rem, inv_card[i]);
           const uint32_t e = rem - qt * cards[i];
@@ -963,7 +966,7 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
     __syncthreads();
     uint32_t w = 1;
 #pragma unroll
-    for (int i = KMAX - 1; i >= 0; --i) {
+    for (int i = KFAST - 1; i >= 0; --i) {
       if (i >= (int)k) continue;
       if (active) {
         const uint32_t r = cards[i];
@@ -1002,7 +1005,7 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
     if (active && lane == 0) G[rank] = gsum;
     if (scores != nullptr) {
 #pragma unroll
-      for (int i = 0; i < KMAX; ++i)
+      for (int i = 0; i < KFAST; ++i)
         if (lane == (uint32_t)i && i < (int)k) {
           s_vars[half][i] = vars[i];
           s_cards[half][i] = cards[i];
@@ -1044,6 +1047,7 @@ __device__ __forceinline__ uint32_t unrank_step(const uint64_t* __restrict__ bin
                                                 uint32_t j, uint64_t rank);
 constexpr uint32_t HIST_LDS_CELLS = 16384;   // 64 KiB of LDS counters
 constexpr uint32_t HIST_ROWS_PER_ITER = 256 * 16;
+template <int KCAP>
 __global__ __launch_bounds__(256) void count_hist_kernel(
     const uint8_t* __restrict__ codes, uint64_t stride, uint64_t num_rows, uint32_t n,
     const uint32_t* __restrict__ card, const uint64_t* __restrict__ binom, uint32_t k,
@@ -1052,11 +1056,11 @@ __global__ __launch_bounds__(256) void count_hist_kernel(
   extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
   const uint32_t table = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
   // subset of this table from its colex rank
-  uint32_t vars[KMAX], wgt[KMAX];
+  uint32_t vars[KCAP], wgt[KCAP];
   {
     uint64_t rem = rank0 + table;
 #pragma unroll
-    for (int j = KMAX; j >= 1; --j) {
+    for (int j = KCAP; j >= 1; --j) {
       vars[j - 1] = 0;
       if (j > (int)k) continue;
       const uint32_t v = unrank_step(binom, n, (uint32_t)j, rem);
@@ -1066,7 +1070,7 @@ __global__ __launch_bounds__(256) void count_hist_kernel(
   }
   uint32_t cells = 1;
 #pragma unroll
-  for (int i = KMAX - 1; i >= 0; --i) {
+  for (int i = KCAP - 1; i >= 0; --i) {
     wgt[i] = 0;
     if (i >= (int)k) continue;
     wgt[i] = cells;  // the last variable has weight 1
@@ -1085,7 +1089,7 @@ __global__ __launch_bounds__(256) void count_hist_kernel(
 #pragma unroll
     for (int b = 0; b < 16; ++b) key[b] = 0;
 #pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
+    for (int i = 0; i < KCAP; ++i) {
       if (i >= (int)k) continue;
       const uint4 x = *reinterpret_cast<const uint4*>(codes + (size_t)vars[i] * stride + base);
       const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
@@ -1138,6 +1142,7 @@ struct BestArgs {                 // every subset size in one launch
   uint32_t block_start[KMAX + 1]; // workgroups [block_start[k-1], block_start[k]) serve size k
   uint32_t kmax;
 };
+template <int KCAP>
 __global__ __launch_bounds__(256) void best_parents_kernel(
     BestArgs args, uint32_t n, const uint64_t* __restrict__ binom,
     unsigned long long* __restrict__ best_key, unsigned long long* __restrict__ best_id, int pass) {
@@ -1164,7 +1169,7 @@ __global__ __launch_bounds__(256) void best_parents_kernel(
   }
   for (uint64_t t = (uint64_t)(blockIdx.x - first_block) * 256 + threadIdx.x; t < nsubsets;
        t += (uint64_t)nblocks * 256) {
-    uint32_t vars[KMAX];
+    uint32_t vars[KCAP];
     uint64_t rem = t;
     for (uint32_t j = k; j >= 1; --j) {
       const uint32_t v = unrank_step(binom, n, j, rem);
@@ -2066,9 +2071,14 @@ obnsl_status run_hist_range(obnsl_data* d, uint32_t k, uint64_t lo, uint64_t hi,
     d->ev_size[d->ev_used] = k;
     auto& ev = d->ev[d->ev_used++];
     HIP_TRY(hipEventRecord(ev.first, d->stream));
-    hipLaunchKernelGGL(count_hist_kernel, dim3(nt * (uint32_t)nchunks), dim3(256), lds, d->stream,
-                       d->codes.p, d->stride, d->N, d->n, d->d_card.p, d->d_binom.p, k, hb->rank0,
-                       (uint32_t)nchunks, rpc, hb->off.p, d->counts.p);
+    if (k <= (uint32_t)KFAST)
+      hipLaunchKernelGGL(count_hist_kernel<KFAST>, dim3(nt * (uint32_t)nchunks), dim3(256), lds, d->stream,
+                         d->codes.p, d->stride, d->N, d->n, d->d_card.p, d->d_binom.p, k, hb->rank0,
+                         (uint32_t)nchunks, rpc, hb->off.p, d->counts.p);
+    else
+      hipLaunchKernelGGL(count_hist_kernel<KMAX>, dim3(nt * (uint32_t)nchunks), dim3(256), lds, d->stream,
+                         d->codes.p, d->stride, d->N, d->n, d->d_card.p, d->d_binom.p, k, hb->rank0,
+                         (uint32_t)nchunks, rpc, hb->off.p, d->counts.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, d->stream));
     hipLaunchKernelGGL(score_tables_kernel, dim3((nt + 3) / 4), dim3(256), 0, d->stream, d->counts.p,
@@ -2094,7 +2104,7 @@ obnsl_status choose_reduced(obnsl_data* d, uint32_t k, bool* use_reduced, uint64
   static const bool allow_reduced = std::getenv("OBNSL_NO_REDUCED") == nullptr;
   static const bool force_hist = std::getenv("OBNSL_FORCE_HIST") != nullptr;
   static const bool force_bits = std::getenv("OBNSL_FORCE_BITGEMM") != nullptr;
-  bool use = allow_reduced && max_cells <= REDUCED_MAX_CELLS && !force_hist;
+  bool use = allow_reduced && max_cells <= REDUCED_MAX_CELLS && !force_hist && k <= (uint32_t)KFAST;
   if (use && !force_bits) {
     Plan* full = nullptr;
     obnsl_status st = build_plan(d, k, 0, 1, true, &full);
@@ -2318,8 +2328,12 @@ obnsl_status obnsl_count(obnsl_data* d, const uint32_t* var_ids, uint32_t k,
   HIP_TRY(hipMemsetAsync(dcnt.p, 0, cells * sizeof(uint32_t), d->stream));
   const uint32_t gx = std::min<uint32_t>((d->wp + 255) / 256, 64);
   const uint32_t gy = (uint32_t)std::min<uint64_t>(cells, 1024);
-  hipLaunchKernelGGL(count_single_kernel, dim3(gx, gy), dim3(256), 0, d->stream, d->planes.p,
-                     d->wp, k, dp.p, dc.p, (uint32_t)cells, dcnt.p, d->ones_plane);
+  if (k <= (uint32_t)KFAST)
+    hipLaunchKernelGGL(count_single_kernel<KFAST>, dim3(gx, gy), dim3(256), 0, d->stream, d->planes.p,
+                       d->wp, k, dp.p, dc.p, (uint32_t)cells, dcnt.p, d->ones_plane);
+  else
+    hipLaunchKernelGGL(count_single_kernel<KMAX>, dim3(gx, gy), dim3(256), 0, d->stream, d->planes.p,
+                       d->wp, k, dp.p, dc.p, (uint32_t)cells, dcnt.p, d->ones_plane);
   HIP_TRY(hipGetLastError());
   std::vector<uint32_t> h(cells);
   HIP_TRY(hipMemcpyAsync(h.data(), dcnt.p, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
@@ -2447,7 +2461,7 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
     }
     st = run_functional(d, own, views, k, max_cells, kind, ess, gprev, g0, d_scores);
     if (st != OBNSL_OK) return st;
-  } else if (std::getenv("OBNSL_FORCE_BITGEMM") == nullptr) {
+  } else if (std::getenv("OBNSL_FORCE_BITGEMM") == nullptr || k > (uint32_t)KFAST) {
     // large tables: per-row LDS histograms over this shard's contiguous rank range
     const uint64_t lo = nsub / num_shards * shard + std::min<uint64_t>(shard, nsub % num_shards);
     const uint64_t hi = nsub / num_shards * (shard + 1) + std::min<uint64_t>(shard + 1, nsub % num_shards);
@@ -2775,8 +2789,12 @@ obnsl_status obnsl_score_subsets(obnsl_data* d, obnsl_score_kind kind, double es
   const uint32_t gy = std::min<uint32_t>(max_cells, m > 64 ? 64u : 1024u);
   for (uint64_t t0 = 0; t0 < m; t0 += (1u << 30)) {
     const uint32_t gx = (uint32_t)std::min<uint64_t>(1u << 30, m - t0);
-    hipLaunchKernelGGL(count_list_kernel, dim3(gx, gy, gz), dim3(256), 0, d->stream, d->planes.p,
-                       d->wp, k, dpb.p + t0 * KMAX, dtd.p + t0, dcnt.p, d->ones_plane);
+    if (k <= (uint32_t)KFAST)
+      hipLaunchKernelGGL(count_list_kernel<KFAST>, dim3(gx, gy, gz), dim3(256), 0, d->stream, d->planes.p,
+                         d->wp, k, dpb.p + t0 * KMAX, dtd.p + t0, dcnt.p, d->ones_plane);
+    else
+      hipLaunchKernelGGL(count_list_kernel<KMAX>, dim3(gx, gy, gz), dim3(256), 0, d->stream, d->planes.p,
+                         d->wp, k, dpb.p + t0 * KMAX, dtd.p + t0, dcnt.p, d->ones_plane);
   }
   HIP_TRY(hipGetLastError());
   if (m) {
@@ -2813,9 +2831,14 @@ static obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_sco
     args.nsubsets[k - 1] = nsub;
     args.block_start[k] = args.block_start[k - 1] + (uint32_t)std::min<uint64_t>((nsub + 255) / 256, 512);
   }
-  for (int pass = 0; pass < 2; ++pass)
-    hipLaunchKernelGGL(best_parents_kernel, dim3(args.block_start[max_parents + 1]), dim3(256), 0,
-                       d->stream, args, d->n, d->d_binom.p, key, id, pass);
+  for (int pass = 0; pass < 2; ++pass) {
+    if (max_parents + 1 <= (uint32_t)KFAST)
+      hipLaunchKernelGGL(best_parents_kernel<KFAST>, dim3(args.block_start[max_parents + 1]), dim3(256), 0,
+                         d->stream, args, d->n, d->d_binom.p, key, id, pass);
+    else
+      hipLaunchKernelGGL(best_parents_kernel<KMAX>, dim3(args.block_start[max_parents + 1]), dim3(256), 0,
+                         d->stream, args, d->n, d->d_binom.p, key, id, pass);
+  }
   HIP_TRY(hipGetLastError());
   return OBNSL_OK;
 }
@@ -2901,8 +2924,6 @@ obnsl_status obnsl_exhaustive_search(obnsl_data* d, obnsl_score_kind kind, doubl
   if (max_parents > n - 1)
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   if (n > 64) return fail(OBNSL_ERR_INVALID_ARGUMENT, "num_of_vars must be in [0, 64]");
-  if (max_parents + 1 > (uint32_t)KMAX)
-    return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be at most OBNSL_MAX_SUBSET - 1 = 7");
   obnsl_status st = check_kind(kind);
   if (st != OBNSL_OK) return st;
   st = set_device(d->device);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libobnsl_engine.so")
 
 BDEU, K2, BIC, AIC = 0, 1, 2, 3
-MAX_SUBSET = 8
+MAX_SUBSET = 32
 
 _STATUS_EXC = {1: ValueError, 2: IndexError, 3: RuntimeError, 4: RuntimeError, 5: ValueError}
 

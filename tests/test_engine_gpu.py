@@ -298,8 +298,11 @@ def test_largest_subset_sizes_and_tiny_problems(engine):
     for k in (7, 8):
         want = oracle.score_all(codes, card, k, nthreads=4)
         assert rel_err(d.score_all(k), want) <= REL, k
+    # nine variables: one table over all of them, through the per-row histogram kernel
+    assert d.count_path(9) == "histogram"
+    assert rel_err(d.score_all(9), oracle.score_all(codes, card, 9)) <= REL
     with pytest.raises(ValueError):
-        d.score_all(9 if engine.MAX_SUBSET < 9 else 10)
+        d.score_all(10)             # more variables than the data set has
     d.close()
     for cards, N in (([3], 100), ([2, 4], 257)):
         codes, card, _, _ = synth.random_bn(cards, N, seed=1, n_arcs=len(cards) - 1)
@@ -467,4 +470,47 @@ def test_extreme_priors_and_a_very_wide_variable(engine):
         cnt = oracle.count(codes, card, vs)
         want = [oracle.local_score(cnt, card[vs], ci, oracle.BDEU, 1e-3) for ci in range(3)]
         assert rel_err(have[t], want) <= REL
+    d.close()
+
+
+def test_subsets_larger_than_eight_variables(engine):
+    """The reference takes any sorted var_ids (include/base/contingency_table.h:34-56)
+    and any max_parents <= n - 1 (src/structure_learning/exhaustive_search.cpp:18-20).
+    Sizes above 8 leave the bit-plane contraction for the per-row histogram kernel:
+    counts bit-exact, scores and the search's optimum as the oracle's."""
+    import oracle
+    from openbnsl_amd import synth
+    cards = [2, 3, 2, 2, 4, 2, 3, 2, 2, 2, 3, 2]
+    codes, card, _, _ = synth.random_bn(cards, 5_000, seed=31)
+    d = engine.Data(codes, card)
+    n = len(cards)
+    rng = np.random.default_rng(3)
+    for k in (9, 10, 11, 12):
+        vs = sorted(rng.choice(n, size=k, replace=False).tolist())
+        want = oracle.count(codes, card, vs)
+        have = d.count(vs)
+        assert np.array_equal(have, want) and int(have.sum()) == 5_000
+        for ci in (0, k // 2, k - 1):
+            w = oracle.local_score(want, card[vs], ci)
+            assert abs(engine.local_score(have, card[vs], ci) - w) <= REL * abs(w)
+        assert d.count_path(k) == "histogram"
+        assert rel_err(d.score_all(k), oracle.score_all(codes, card, k, nthreads=4)) <= REL, k
+        subs = np.array([sorted(rng.choice(n, size=k, replace=False).tolist()) for _ in range(3)], dtype=np.uint32)
+        got = d.score_subsets(subs)
+        for t, s in enumerate(subs):
+            cnt = oracle.count(codes, card, s)
+            assert rel_err(got[t], [oracle.local_score(cnt, card[s], ci) for ci in range(k)]) <= REL
+    # the search with no bound on the number of parents (max_parents = n - 1)
+    parents, total = d.exhaustive_search(n - 1)
+    _, want_total = oracle.exhaustive_search(codes, card, n - 1)
+    assert abs(total - want_total) <= REL * abs(want_total)
+    # per-node best parent sets over every subset size
+    import torch
+    tabs = [d.score_all(k) for k in range(1, n + 1)]
+    dev = [torch.from_numpy(t.reshape(-1)).cuda() for t in tabs]
+    sc, sz, rk = d.best_parents([t.data_ptr() for t in dev], n - 1)
+    best = np.full(n, -np.inf)
+    for k, t in enumerate(tabs, start=1):
+        np.maximum.at(best, oracle.enumerate_subsets(n, k).reshape(-1), t.reshape(-1))
+    assert np.array_equal(sc, best)
     d.close()

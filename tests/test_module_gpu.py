@@ -27,8 +27,6 @@ def test_contingency_table_and_local_score(ob, golden, frame):
     w = ob.base.DataframeWrapper(df)
     for tb in rec["tables"]:
         vs = tb["var_ids"]
-        if len(vs) > 8:
-            continue
         ct = ob.base.ContingencyTable(vs, w)
         assert ct.var_ids == vs and ct.cardinalities == tb["cardinalities"]
         assert {str(k): v for k, v in ct.counts.items()} == tb["counts"]
