@@ -44,6 +44,41 @@ ASIA_EDGES = [("asia", "tub"), ("smoke", "lung"), ("smoke", "bronc"), ("tub", "e
               ("lung", "either"), ("either", "xray"), ("either", "dysp"), ("bronc", "dysp")]
 
 
+def cancer(N=100_000, seed=0):
+    """The five-variable CANCER network (Korb & Nicholson): Pollution -> Cancer <-
+    Smoker, Cancer -> Xray, Cancer -> Dyspnoea; columns sorted by name, values
+    coded by lexicographic rank of their labels as the reference codes them.
+    Returns (codes, card, names, parent lists)."""
+    rng = np.random.default_rng(seed)
+    u = {k: rng.random(N) for k in ("Pollution", "Smoker", "Cancer", "Xray", "Dyspnoea")}
+    high = u["Pollution"] < 0.1                       # labels "high" < "low"
+    smoker = u["Smoker"] < 0.3                        # "False" < "True"
+    p_c = np.where(high, np.where(smoker, 0.05, 0.02), np.where(smoker, 0.03, 0.001))
+    cancer_ = u["Cancer"] < p_c
+    xray_pos = u["Xray"] < np.where(cancer_, 0.9, 0.2)   # "negative" < "positive"
+    dysp = u["Dyspnoea"] < np.where(cancer_, 0.65, 0.3)
+    cols = {"Cancer": cancer_.astype(np.uint8), "Dyspnoea": dysp.astype(np.uint8),
+            "Pollution": (~high).astype(np.uint8), "Smoker": smoker.astype(np.uint8),
+            "Xray": xray_pos.astype(np.uint8)}
+    names = sorted(cols)
+    codes = np.ascontiguousarray(np.stack([cols[k] for k in names]))
+    idx = {k: i for i, k in enumerate(names)}
+    parents = [[] for _ in names]
+    for a, b in (("Pollution", "Cancer"), ("Smoker", "Cancer"), ("Cancer", "Xray"), ("Cancer", "Dyspnoea")):
+        parents[idx[b]].append(idx[a])
+    return codes, np.array([2] * 5, dtype=np.uint32), names, [sorted(p) for p in parents]
+
+
+# State counts of the 20-node CHILD network (25 arcs, in-degree <= 2).
+CHILD_CARDS = [2, 6, 3, 3, 4, 3, 3, 3, 2, 2, 3, 3, 2, 3, 2, 3, 3, 5, 2, 2]
+
+
+def child_shaped(N=100_000, seed=0):
+    """20 variables with CHILD's state counts, 25 arcs, at most two parents each.
+    Returns (codes, card, names, parent lists of the generating DAG)."""
+    return random_bn(CHILD_CARDS, N, seed=seed, n_arcs=25, max_indegree=2, min_prob=0.02)
+
+
 def random_dag(n, n_arcs, max_indegree, rng):
     """Random DAG over 0..n-1 in index order: parents[v] subset of {0..v-1}."""
     parents = [[] for _ in range(n)]
