@@ -20,10 +20,10 @@ else
 all: $(ENGINE) oracle
 endif
 
-ENGINE_SRC := openbnsl_amd/csrc/engine.hip openbnsl_amd/csrc/anneal.cpp openbnsl_amd/csrc/score_file.cpp
+ENGINE_SRC := openbnsl_amd/csrc/engine.hip openbnsl_amd/csrc/group.hip openbnsl_amd/csrc/anneal.cpp openbnsl_amd/csrc/score_file.cpp
 $(ENGINE): $(ENGINE_SRC) openbnsl_amd/csrc/engine_internal.h include/obnsl_engine.h
 	mkdir -p openbnsl_amd/lib
-	$(HIPCC) $(HIPFLAGS) -Iopenbnsl_amd/csrc -pthread -shared $(ENGINE_SRC) -o $@
+	$(HIPCC) $(HIPFLAGS) -Iopenbnsl_amd/csrc -pthread -shared $(ENGINE_SRC) -ldl -o $@
 
 $(PYMOD): $(HOST_SRC) $(HOST_HDR) $(ENGINE)
 	g++ -O2 -std=c++17 -fPIC -shared -fvisibility=hidden -Wall -Iinclude -Iopenbnsl_amd/host \

@@ -237,6 +237,54 @@ obnsl_status obnsl_exhaustive_search(obnsl_data* d, obnsl_score_kind kind, doubl
                                      uint32_t max_parents, uint64_t* parents_out,
                                      double* total_score_out);
 
+/* The second half of obnsl_exhaustive_search alone: the subset dynamic program
+ * and the back-track (exhaustive_search.cpp:75-148) on score tables that are
+ * already on the data set's device -- d_tables[k-1] = the table of subset size
+ * k as obnsl_score_all writes it, k = 1..max_parents+1.  This is what runs on
+ * one device after several have scored their shards. */
+obnsl_status obnsl_exhaustive_search_tables(obnsl_data* d, const double* const* d_tables,
+                                            uint32_t max_parents, uint64_t* parents_out,
+                                            double* total_score_out);
+
+/* ---- several GPUs behind one call --------------------------------------
+ * The reference's entry point (bindings/submodules/structure_learning.cpp:12-18
+ * -> exhaustive_search.cpp:14) is one thread on one device.  A group is one
+ * host process driving `num_devices` GPUs: rank r = devices[r] holds a replica
+ * of the data matrix (obnsl_data_create's arguments, host memory) and scores
+ * shard r of every subset size; the ranks exchange over RCCL (xGMI): an
+ * all-reduce of one count table before scoring, an all-gather of the per-node
+ * records (or an all-reduce of the score tables) after it.  A group in which a
+ * device appears twice (ranks sharing a GPU: how a one-GPU box rehearses the
+ * sharded pass) or OBNSL_GROUP_EXCHANGE=copy exchanges by device copies
+ * instead.  Calls on a group are serialised by the caller, like calls on a
+ * data set. */
+typedef struct obnsl_group obnsl_group;
+obnsl_status obnsl_group_create(const uint8_t* codes, uint64_t num_rows, uint64_t col_stride,
+                                uint32_t num_vars, const uint32_t* cardinalities,
+                                const int* devices, uint32_t num_devices, obnsl_group** out);
+obnsl_status obnsl_group_destroy(obnsl_group* g);
+/* Either output may be null.  *uses_rccl: 1 = RCCL collectives, 0 = device copies. */
+obnsl_status obnsl_group_info(const obnsl_group* g, uint32_t* num_devices, int* uses_rccl);
+
+/* The hot path over the whole group: count, score every (child, parent set)
+ * with at most max_parents parents (sharded), reduce to per-node best parent
+ * sets, combine over the ranks.  Outputs (host) as obnsl_best_parents.
+ * repack != 0 rebuilds the row bitmaps first (nothing cached is reused). */
+obnsl_status obnsl_group_best_parents(obnsl_group* g, obnsl_score_kind kind, double ess,
+                                      uint32_t max_parents, int repack, double* best_score,
+                                      uint32_t* best_size, uint64_t* best_rank);
+/* The complete score tables (the ranks' shards merged): tables_out[k-1] (host,
+ * k * C(num_vars, k) doubles, or null to skip a size), k = 1..max_parents+1. */
+obnsl_status obnsl_group_score_tables(obnsl_group* g, obnsl_score_kind kind, double ess,
+                                      uint32_t max_parents, int repack, double* const* tables_out);
+/* exhaustive_search(df, score_type, max_parents) with the scoring phase
+ * (exhaustive_search.cpp:47-73) sharded over the group and the subset dynamic
+ * program (:75-148, not shardable) on rank 0.  Outputs and errors as
+ * obnsl_exhaustive_search. */
+obnsl_status obnsl_group_exhaustive_search(obnsl_group* g, obnsl_score_kind kind, double ess,
+                                           uint32_t max_parents, uint64_t* parents_out,
+                                           double* total_score_out);
+
 /* Replaces simulated_annealing(df, score_type, max_parents, max_iters,
  * init_temp, cooling_rate, is_deterministic, seed, num_chains)
  * (src/structure_learning/simulated_annealing.cpp:100-159; defaults of its

@@ -603,11 +603,16 @@ __global__ __launch_bounds__(256) void bitgemm_mfma_kernel(
 // Dense counts of one explicit subset: counts[cell] += popc(AND of the cell's
 // planes) over this block's share of the words.  Generic and simple: it serves
 // the one-table calls (ContingencyTable(var_ids, df)), not the batch path.
+struct OneTable {   // a single explicit subset, passed by value (no upload per call)
+  uint32_t pbase[KMAX];
+  uint32_t cards[KMAX];
+};
 template <int KCAP>
 __global__ __launch_bounds__(256) void count_single_kernel(
-    const uint32_t* __restrict__ planes, uint32_t wp, uint32_t k, const uint32_t* __restrict__ pbase,
-    const uint32_t* __restrict__ cards, uint32_t cells, uint32_t* __restrict__ counts,
-    uint32_t ones_plane) {
+    const uint32_t* __restrict__ planes, uint32_t wp, uint32_t k, OneTable ot, uint32_t cells,
+    uint32_t* __restrict__ counts, uint32_t ones_plane) {
+  const uint32_t* pbase = ot.pbase;
+  const uint32_t* cards = ot.cards;
   __shared__ uint32_t red[4];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t cell = blockIdx.y; cell < cells; cell += gridDim.y) {
@@ -806,6 +811,12 @@ __global__ __launch_bounds__(256) void score_tables_kernel(
   uint32_t cards[KMAX];
   for (uint32_t j = 0; j < td.k; ++j) cards[j] = td.cards[j];
   score_table(counts + td.off, td.k, cards, kind, ess, lane, scores + t * td.k);
+}
+
+// One table whose descriptor comes by value (obnsl_local_score).
+__global__ __launch_bounds__(64) void score_one_kernel(const uint32_t* __restrict__ counts, TableDesc td,
+                                                       int kind, double ess, double* __restrict__ scores) {
+  score_table(counts, td.k, td.cards, kind, ess, threadIdx.x & 63, scores);
 }
 
 // ---- reduced ("non-reference states only") tables -> full tables -> scores
@@ -1446,6 +1457,10 @@ struct obnsl_data {
   DevBuf<uint8_t> codes;
   DevBuf<uint32_t> planes, d_card, d_plane_base, counts;
   DevBuf<unsigned long long> best_key;           // per-node arg-max scratch of obnsl_best_parents
+  // scratch of the one-table / explicit-list entry points: grows, never shrinks
+  DevBuf<uint32_t> one_cnt, list_pb, list_cnt;
+  DevBuf<TableDesc> list_td;
+  DevBuf<double> list_out;
   DevBuf<uint64_t> d_binom;
   std::map<std::tuple<uint32_t, uint32_t, uint32_t, bool>, std::unique_ptr<Plan>> plans;
   std::map<std::tuple<uint32_t, uint64_t, uint64_t>, std::vector<std::unique_ptr<HistBatch>>> hist_plans;
@@ -2321,19 +2336,23 @@ obnsl_status obnsl_count(obnsl_data* d, const uint32_t* var_ids, uint32_t k,
   if (cells > cap) return fail(OBNSL_ERR_INVALID_ARGUMENT, "counts_out is too small");
   obnsl_status st = set_device(d->device);
   if (st != OBNSL_OK) return st;
-  DevBuf<uint32_t> dp, dc, dcnt;
-  HIP_TRY(dp.upload(pbase));
-  HIP_TRY(dc.upload(cards));
+  OneTable ot;
+  std::memset(&ot, 0, sizeof(ot));
+  for (uint32_t i = 0; i < k; ++i) {
+    ot.pbase[i] = pbase[i];
+    ot.cards[i] = cards[i];
+  }
+  DevBuf<uint32_t>& dcnt = d->one_cnt;
   HIP_TRY(dcnt.ensure(cells));
   HIP_TRY(hipMemsetAsync(dcnt.p, 0, cells * sizeof(uint32_t), d->stream));
   const uint32_t gx = std::min<uint32_t>((d->wp + 255) / 256, 64);
   const uint32_t gy = (uint32_t)std::min<uint64_t>(cells, 1024);
   if (k <= (uint32_t)KFAST)
     hipLaunchKernelGGL(count_single_kernel<KFAST>, dim3(gx, gy), dim3(256), 0, d->stream, d->planes.p,
-                       d->wp, k, dp.p, dc.p, (uint32_t)cells, dcnt.p, d->ones_plane);
+                       d->wp, k, ot, (uint32_t)cells, dcnt.p, d->ones_plane);
   else
     hipLaunchKernelGGL(count_single_kernel<KMAX>, dim3(gx, gy), dim3(256), 0, d->stream, d->planes.p,
-                       d->wp, k, dp.p, dc.p, (uint32_t)cells, dcnt.p, d->ones_plane);
+                       d->wp, k, ot, (uint32_t)cells, dcnt.p, d->ones_plane);
   HIP_TRY(hipGetLastError());
   std::vector<uint32_t> h(cells);
   HIP_TRY(hipMemcpyAsync(h.data(), dcnt.p, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
@@ -2370,17 +2389,24 @@ obnsl_status obnsl_local_score(int device, const uint64_t* counts, const uint32_
     if (counts[i] >= (1ull << 32)) return fail(OBNSL_ERR_UNSUPPORTED, "count exceeds 2^32-1");
     h[i] = (uint32_t)counts[i];
   }
-  DevBuf<uint32_t> dcnt;
-  DevBuf<TableDesc> dtd;
-  DevBuf<double> dout;
-  HIP_TRY(dcnt.upload(h));
-  HIP_TRY(dtd.upload(std::vector<TableDesc>{td}));
-  HIP_TRY(dout.ensure(KMAX));
-  hipLaunchKernelGGL(score_tables_kernel, dim3(1), dim3(256), 0, nullptr, dcnt.p, dtd.p,
-                     (uint64_t)1, (int)kind, ess, dout.p);
+  // per-device scratch kept for the life of the process (one call at a time per device)
+  struct Scratch {
+    DevBuf<uint32_t> cnt;
+    DevBuf<double> out;
+  };
+  static std::mutex mu;
+  static Scratch* scratch_of[MAX_DEVICES] = {nullptr};
+  if (device >= MAX_DEVICES) return fail(OBNSL_ERR_INVALID_ARGUMENT, "device index out of range");
+  std::lock_guard<std::mutex> lock(mu);
+  if (!scratch_of[device]) scratch_of[device] = new Scratch();
+  Scratch& sc = *scratch_of[device];
+  HIP_TRY(sc.cnt.ensure(cells));
+  HIP_TRY(sc.out.ensure(KMAX));
+  HIP_TRY(hipMemcpyAsync(sc.cnt.p, h.data(), cells * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
+  hipLaunchKernelGGL(score_one_kernel, dim3(1), dim3(64), 0, nullptr, sc.cnt.p, td, (int)kind, ess, sc.out.p);
   HIP_TRY(hipGetLastError());
   double res[KMAX];
-  HIP_TRY(hipMemcpy(res, dout.p, k * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(res, sc.out.p, k * sizeof(double), hipMemcpyDeviceToHost));
   *score_out = res[child_idx];
   return OBNSL_OK;
 }
@@ -2769,14 +2795,18 @@ obnsl_status obnsl_score_subsets(obnsl_data* d, obnsl_score_kind kind, double es
     }
     off += cells;
   }
-  DevBuf<uint32_t> dpb, dcnt;
-  DevBuf<TableDesc> dtd;
-  DevBuf<double> dout;
+  DevBuf<uint32_t>&dpb = d->list_pb, &dcnt = d->list_cnt;
+  DevBuf<TableDesc>& dtd = d->list_td;
+  DevBuf<double>& dout = d->list_out;
   uint32_t max_cells = 1;
   for (uint64_t t = 0; t < m; ++t)
     max_cells = std::max<uint32_t>(max_cells, (uint32_t)((t + 1 < m ? tds[t + 1].off : off) - tds[t].off));
-  HIP_TRY(dpb.upload(pb));
-  HIP_TRY(dtd.upload(tds));
+  HIP_TRY(dpb.ensure(std::max<size_t>(pb.size(), 1)));
+  HIP_TRY(dtd.ensure(std::max<size_t>(tds.size(), 1)));
+  if (m) {
+    HIP_TRY(hipMemcpyAsync(dpb.p, pb.data(), pb.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(dtd.p, tds.data(), tds.size() * sizeof(TableDesc), hipMemcpyHostToDevice, d->stream));
+  }
   HIP_TRY(dcnt.ensure(std::max<uint64_t>(off, 1)));
   HIP_TRY(dout.ensure(std::max<uint64_t>(m * k, 1)));
   HIP_TRY(hipMemsetAsync(dcnt.p, 0, off * sizeof(uint32_t), d->stream));
@@ -2915,18 +2945,14 @@ obnsl_status obnsl_combine_best_device(obnsl_data* d, const double* d_parts, uin
   return OBNSL_OK;
 }
 
-obnsl_status obnsl_exhaustive_search(obnsl_data* d, obnsl_score_kind kind, double ess,
-                                     uint32_t max_parents, uint64_t* parents_out,
-                                     double* total_score_out) {
-  if (!d || !parents_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+// Argument and capacity checks shared by the two search entry points.
+static obnsl_status search_checks(obnsl_data* d, uint32_t max_parents) {
   const uint32_t n = d->n;
   // reference: exhaustive_search.cpp:18-23
   if (max_parents > n - 1)
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   if (n > 64) return fail(OBNSL_ERR_INVALID_ARGUMENT, "num_of_vars must be in [0, 64]");
-  obnsl_status st = check_kind(kind);
-  if (st != OBNSL_OK) return st;
-  st = set_device(d->device);
+  obnsl_status st = set_device(d->device);
   if (st != OBNSL_OK) return st;
   // the tables grow as n * 2^n (the reference's :30-40 need n * 2^n * 16 bytes
   // and overflow `1 << n` from n = 31): refuse what the device cannot hold
@@ -2942,18 +2968,23 @@ obnsl_status obnsl_exhaustive_search(obnsl_data* d, obnsl_score_kind kind, doubl
     return fail(OBNSL_ERR_INVALID_ARGUMENT,
                 "num_of_vars too large for the exact subset dynamic program on this device "
                 "(its tables grow as n * 2^n)");
-  // scores of every subset size the search asks for, on the device
-  std::vector<DevBuf<double>> tables(max_parents + 1);
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_exhaustive_search_tables(obnsl_data* d, const double* const* d_tables,
+                                            uint32_t max_parents, uint64_t* parents_out,
+                                            double* total_score_out) {
+  if (!d || !d_tables || !parents_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  obnsl_status st = search_checks(d, max_parents);
+  if (st != OBNSL_OK) return st;
+  const uint32_t n = d->n;
+  const uint64_t combs = 1ull << n, half = combs >> 1;
   DpScores sc;
   std::memset(&sc, 0, sizeof(sc));
   sc.max_scored = max_parents + 1;
-  st = obnsl_precount(d, max_parents + 1, 0, 1);
-  if (st != OBNSL_OK) return st;
   for (uint32_t k = 1; k <= max_parents + 1; ++k) {
-    HIP_TRY(tables[k - 1].ensure(std::max<uint64_t>(binom_host(n, k) * k, 1)));
-    st = obnsl_score_all(d, kind, ess, k, 0, 1, tables[k - 1].p, 1);
-    if (st != OBNSL_OK) return st;
-    sc.tbl[k - 1] = tables[k - 1].p;
+    if (!d_tables[k - 1]) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null score table");
+    sc.tbl[k - 1] = d_tables[k - 1];
   }
   DevBuf<double> best_gs, bls, total;
   DevBuf<signed char> best_ch;
@@ -2979,6 +3010,29 @@ obnsl_status obnsl_exhaustive_search(obnsl_data* d, obnsl_score_kind kind, doubl
   HIP_TRY(hipStreamSynchronize(d->stream));
   if (total_score_out) *total_score_out = tot;
   return OBNSL_OK;
+}
+
+obnsl_status obnsl_exhaustive_search(obnsl_data* d, obnsl_score_kind kind, double ess,
+                                     uint32_t max_parents, uint64_t* parents_out,
+                                     double* total_score_out) {
+  if (!d || !parents_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  obnsl_status st = search_checks(d, max_parents);
+  if (st != OBNSL_OK) return st;
+  st = check_kind(kind);
+  if (st != OBNSL_OK) return st;
+  const uint32_t n = d->n;
+  // scores of every subset size the search asks for, on the device
+  std::vector<DevBuf<double>> tables(max_parents + 1);
+  std::vector<const double*> ptrs(max_parents + 1);
+  st = obnsl_precount(d, max_parents + 1, 0, 1);
+  if (st != OBNSL_OK) return st;
+  for (uint32_t k = 1; k <= max_parents + 1; ++k) {
+    HIP_TRY(tables[k - 1].ensure(std::max<uint64_t>(binom_host(n, k) * k, 1)));
+    st = obnsl_score_all(d, kind, ess, k, 0, 1, tables[k - 1].p, 1);
+    if (st != OBNSL_OK) return st;
+    ptrs[k - 1] = tables[k - 1].p;
+  }
+  return obnsl_exhaustive_search_tables(d, ptrs.data(), max_parents, parents_out, total_score_out);
 }
 
 obnsl_status obnsl_count_path(obnsl_data* d, uint32_t k, int* path_out) {

@@ -1,0 +1,489 @@
+// group.hip -- one host process driving several GPUs (include/obnsl_engine.h,
+// obnsl_group_*).
+//
+// The reference is a single-threaded, single-device program
+// (src/structure_learning/exhaustive_search.cpp:47-130 has no parallel loop).
+// Here the subsets of every size are split over the devices of a group; rank r
+// (= devices[r]) holds a replica of the data matrix and works on its own
+// stream.  One pass:
+//
+//   every rank : pack -> count (largest size: its shard; second largest: its
+//                slice; smaller sizes whole)                       [asynchronous]
+//   exchange 1 : all-reduce(sum, uint32) of the second-largest count table
+//   every rank : score its shard of every size -> per-node bests of the shard
+//   exchange 2 : all-gather of the per-node records (3 doubles per node)
+//   every rank : deterministic combine (score, then fewer parents, then rank)
+//
+// The exchanges go through RCCL (ncclCommInitAll over the group's devices, one
+// communicator per rank, group calls from this one thread).  RCCL is opened at
+// run time (dlopen), so the library loads where it is absent and binds to the
+// copy a host program already holds (PyTorch ships its own).  RCCL refuses a
+// device that appears twice; such a group -- several ranks sharing one GPU, which
+// is how a box with one GPU rehearses the sharded pass -- and a group of one
+// rank exchange by device copies and an add kernel instead ("copy" exchange; it
+// can also be forced with OBNSL_GROUP_EXCHANGE=copy).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "engine_internal.h"
+#include "obnsl_engine.h"
+
+namespace {
+
+using obnsl_internal::fail;
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(OBNSL_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define OB_TRY(expr)                   \
+  do {                                 \
+    obnsl_status s_ = (expr);          \
+    if (s_ != OBNSL_OK) return s_;     \
+  } while (0)
+
+// ---- the few RCCL entry points used, bound at run time
+typedef void* nccl_comm_t;
+struct Rccl {
+  void* lib = nullptr;
+  int (*CommInitAll)(nccl_comm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(nccl_comm_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok() const { return lib != nullptr; }
+};
+// rccl.h: ncclSum = 0, ncclMax = 2; ncclUint32 = 3, ncclFloat64 = 8
+constexpr int kSum = 0, kMax = 2, kU32 = 3, kF64 = 8;
+
+Rccl& rccl() {
+  static Rccl r = [] {
+    Rccl x;
+    void* h = nullptr;
+    // the copy the process already holds first (PyTorch's), then the system's
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return x;
+    auto sym = [&](const char* n) { return dlsym(h, n); };
+    x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
+    x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+    x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
+    x.AllGather = reinterpret_cast<decltype(x.AllGather)>(sym("ncclAllGather"));
+    x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
+    x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
+    x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+    if (x.CommInitAll && x.CommDestroy && x.AllReduce && x.AllGather && x.GroupStart && x.GroupEnd)
+      x.lib = h;
+    return x;
+  }();
+  return r;
+}
+
+__global__ void add_u32_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+    dst[i] += src[i];
+}
+__global__ void max_f64_kernel(double* __restrict__ dst, const double* __restrict__ src, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+    dst[i] = fmax(dst[i], src[i]);
+}
+__global__ void fill_f64_kernel(double* __restrict__ dst, double v, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+    dst[i] = v;
+}
+
+struct Rank {
+  int device = 0;
+  obnsl_data* data = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ready = nullptr, done = nullptr;
+  nccl_comm_t comm = nullptr;
+  std::vector<double*> tables;   // [k-1]: C(n,k) * k doubles, device
+  std::vector<uint64_t> table_len;
+  double* best = nullptr;        // n * 3
+  double* gathered = nullptr;    // world * n * 3
+  double* combined = nullptr;    // n * 3
+  uint32_t* stage = nullptr;     // copy exchange across devices: a peer's table lands here
+  uint64_t stage_words = 0;
+};
+
+}  // namespace
+
+struct obnsl_group {
+  uint32_t n = 0;
+  uint64_t N = 0;
+  std::vector<Rank> ranks;
+  bool use_rccl = false;
+  uint32_t tables_for = 0;  // score tables are allocated for subset sizes 1..tables_for
+  ~obnsl_group() {
+    for (Rank& r : ranks) {
+      (void)hipSetDevice(r.device);
+      if (r.stream) (void)hipStreamSynchronize(r.stream);
+      if (r.comm && rccl().ok()) (void)rccl().CommDestroy(r.comm);
+      if (r.data) (void)obnsl_data_destroy(r.data);
+      for (double* t : r.tables)
+        if (t) (void)hipFree(t);
+      if (r.best) (void)hipFree(r.best);
+      if (r.gathered) (void)hipFree(r.gathered);
+      if (r.combined) (void)hipFree(r.combined);
+      if (r.stage) (void)hipFree(r.stage);
+      if (r.ready) (void)hipEventDestroy(r.ready);
+      if (r.done) (void)hipEventDestroy(r.done);
+      if (r.stream) (void)hipStreamDestroy(r.stream);
+    }
+  }
+};
+
+namespace {
+
+obnsl_status nccl_check(int rc, const char* what) {
+  if (rc == 0) return OBNSL_OK;
+  const char* msg = rccl().GetErrorString ? rccl().GetErrorString(rc) : "error";
+  return fail(OBNSL_ERR_RUNTIME, std::string(what) + ": " + msg);
+}
+
+obnsl_status ensure_tables(obnsl_group* g, uint32_t kmax) {
+  if (kmax <= g->tables_for) return OBNSL_OK;
+  for (Rank& r : g->ranks) {
+    HIP_TRY(hipSetDevice(r.device));
+    r.tables.resize(kmax, nullptr);
+    r.table_len.resize(kmax, 0);
+    for (uint32_t k = g->tables_for + 1; k <= kmax; ++k) {
+      const uint64_t len = obnsl_binomial(g->n, k) * k;
+      r.table_len[k - 1] = len;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&r.tables[k - 1]), std::max<uint64_t>(len, 1) * sizeof(double)));
+    }
+  }
+  g->tables_for = kmax;
+  return OBNSL_OK;
+}
+
+// rank 0's stream waits for everything queued on the other ranks' streams, or
+// the other way round
+obnsl_status fan_in(obnsl_group* g) {
+  for (size_t r = 1; r < g->ranks.size(); ++r) {
+    HIP_TRY(hipSetDevice(g->ranks[r].device));
+    HIP_TRY(hipEventRecord(g->ranks[r].ready, g->ranks[r].stream));
+    HIP_TRY(hipSetDevice(g->ranks[0].device));
+    HIP_TRY(hipStreamWaitEvent(g->ranks[0].stream, g->ranks[r].ready, 0));
+  }
+  return OBNSL_OK;
+}
+obnsl_status fan_out(obnsl_group* g) {
+  HIP_TRY(hipSetDevice(g->ranks[0].device));
+  HIP_TRY(hipEventRecord(g->ranks[0].done, g->ranks[0].stream));
+  for (size_t r = 1; r < g->ranks.size(); ++r) {
+    HIP_TRY(hipSetDevice(g->ranks[r].device));
+    HIP_TRY(hipStreamWaitEvent(g->ranks[r].stream, g->ranks[0].done, 0));
+  }
+  return OBNSL_OK;
+}
+
+// Sum of the ranks' uint32 tables (`words` each, at ptr[r]), left in every rank's table.
+obnsl_status all_reduce_sum_u32(obnsl_group* g, const std::vector<uint32_t*>& ptr, uint64_t words) {
+  const size_t W = g->ranks.size();
+  if (W == 1 && !g->use_rccl) return OBNSL_OK;
+  if (g->use_rccl) {
+    OB_TRY(nccl_check(rccl().GroupStart(), "ncclGroupStart"));
+    for (size_t r = 0; r < W; ++r)
+      OB_TRY(nccl_check(rccl().AllReduce(ptr[r], ptr[r], words, kU32, kSum, g->ranks[r].comm, g->ranks[r].stream),
+                        "ncclAllReduce"));
+    return nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+  }
+  // copy exchange: rank 0 adds the others' tables into its own, then hands the sum back
+  OB_TRY(fan_in(g));
+  Rank& r0 = g->ranks[0];
+  HIP_TRY(hipSetDevice(r0.device));
+  for (size_t r = 1; r < W; ++r) {
+    const uint32_t* src = ptr[r];
+    if (g->ranks[r].device != r0.device) {
+      if (r0.stage_words < words) {
+        if (r0.stage) HIP_TRY(hipFree(r0.stage));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&r0.stage), words * sizeof(uint32_t)));
+        r0.stage_words = words;
+      }
+      HIP_TRY(hipMemcpyPeerAsync(r0.stage, r0.device, ptr[r], g->ranks[r].device, words * sizeof(uint32_t), r0.stream));
+      src = r0.stage;
+    }
+    hipLaunchKernelGGL(add_u32_kernel, dim3(1024), dim3(256), 0, r0.stream, ptr[0], src, words);
+    HIP_TRY(hipGetLastError());
+  }
+  for (size_t r = 1; r < W; ++r)
+    HIP_TRY(hipMemcpyPeerAsync(ptr[r], g->ranks[r].device, ptr[0], r0.device, words * sizeof(uint32_t), r0.stream));
+  return fan_out(g);
+}
+
+// Every rank's `count` doubles at send[r] -> all of them, rank after rank, at recv[r].
+obnsl_status all_gather_f64(obnsl_group* g, const std::vector<double*>& send, const std::vector<double*>& recv,
+                            uint64_t count) {
+  const size_t W = g->ranks.size();
+  if (g->use_rccl) {
+    OB_TRY(nccl_check(rccl().GroupStart(), "ncclGroupStart"));
+    for (size_t r = 0; r < W; ++r)
+      OB_TRY(nccl_check(rccl().AllGather(send[r], recv[r], count, kF64, g->ranks[r].comm, g->ranks[r].stream),
+                        "ncclAllGather"));
+    return nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+  }
+  OB_TRY(fan_in(g));
+  Rank& r0 = g->ranks[0];
+  HIP_TRY(hipSetDevice(r0.device));
+  for (size_t r = 0; r < W; ++r)
+    HIP_TRY(hipMemcpyPeerAsync(recv[0] + r * count, r0.device, send[r], g->ranks[r].device, count * sizeof(double),
+                               r0.stream));
+  for (size_t r = 1; r < W; ++r)
+    HIP_TRY(hipMemcpyPeerAsync(recv[r], g->ranks[r].device, recv[0], r0.device, W * count * sizeof(double), r0.stream));
+  return fan_out(g);
+}
+
+// Element-wise maximum of the ranks' double tables, left in every rank's table
+// (score tables whose foreign entries are -inf: the maximum is the whole table).
+obnsl_status all_reduce_max_f64(obnsl_group* g, const std::vector<double*>& ptr, uint64_t count) {
+  const size_t W = g->ranks.size();
+  if (W == 1 && !g->use_rccl) return OBNSL_OK;
+  if (g->use_rccl) {
+    OB_TRY(nccl_check(rccl().GroupStart(), "ncclGroupStart"));
+    for (size_t r = 0; r < W; ++r)
+      OB_TRY(nccl_check(rccl().AllReduce(ptr[r], ptr[r], count, kF64, kMax, g->ranks[r].comm, g->ranks[r].stream),
+                        "ncclAllReduce"));
+    return nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+  }
+  OB_TRY(fan_in(g));
+  Rank& r0 = g->ranks[0];
+  HIP_TRY(hipSetDevice(r0.device));
+  for (size_t r = 1; r < W; ++r) {
+    const double* src = ptr[r];
+    if (g->ranks[r].device != r0.device) {
+      const uint64_t words = count * 2;
+      if (r0.stage_words < words) {
+        if (r0.stage) HIP_TRY(hipFree(r0.stage));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&r0.stage), words * sizeof(uint32_t)));
+        r0.stage_words = words;
+      }
+      HIP_TRY(hipMemcpyPeerAsync(r0.stage, r0.device, ptr[r], g->ranks[r].device, count * sizeof(double), r0.stream));
+      src = reinterpret_cast<const double*>(r0.stage);
+    }
+    hipLaunchKernelGGL(max_f64_kernel, dim3(1024), dim3(256), 0, r0.stream, ptr[0], src, count);
+    HIP_TRY(hipGetLastError());
+  }
+  for (size_t r = 1; r < W; ++r)
+    HIP_TRY(hipMemcpyPeerAsync(ptr[r], g->ranks[r].device, ptr[0], r0.device, count * sizeof(double), r0.stream));
+  return fan_out(g);
+}
+
+// pack (optional) -> sharded counting -> exchange 1 -> sharded scoring of sizes 1..kmax
+obnsl_status score_pass(obnsl_group* g, obnsl_score_kind kind, double ess, uint32_t kmax, int repack) {
+  const uint32_t W = (uint32_t)g->ranks.size();
+  OB_TRY(ensure_tables(g, kmax));
+  uint32_t sum_size = 0;
+  uint64_t sum_cells = 0;
+  for (uint32_t r = 0; r < W; ++r) {
+    Rank& rk = g->ranks[r];
+    HIP_TRY(hipSetDevice(rk.device));
+    if (repack) OB_TRY(obnsl_data_pack(rk.data));
+    // entries of the other ranks' shards stay -inf
+    for (uint32_t k = 1; k <= kmax; ++k) {
+      hipLaunchKernelGGL(fill_f64_kernel, dim3(512), dim3(256), 0, rk.stream, rk.tables[k - 1], -INFINITY,
+                         rk.table_len[k - 1]);
+      HIP_TRY(hipGetLastError());
+    }
+    uint32_t sz = 0;
+    uint64_t cells = 0;
+    OB_TRY(obnsl_precount_sharded(rk.data, kmax, r, W, &sz, &cells));
+    if (r == 0) {
+      sum_size = sz;
+      sum_cells = cells;
+    } else if (sz != sum_size || cells != sum_cells) {
+      return fail(OBNSL_ERR_RUNTIME, "internal: ranks disagree on the table to sum");
+    }
+  }
+  if (sum_size) {
+    std::vector<uint32_t*> ptr(W);
+    for (uint32_t r = 0; r < W; ++r) {
+      uint64_t cells = 0;
+      HIP_TRY(hipSetDevice(g->ranks[r].device));
+      OB_TRY(obnsl_counts_pointer(g->ranks[r].data, sum_size, &ptr[r], &cells));
+    }
+    OB_TRY(all_reduce_sum_u32(g, ptr, sum_cells));
+    for (uint32_t r = 0; r < W; ++r) OB_TRY(obnsl_counts_mark_summed(g->ranks[r].data, sum_size));
+  }
+  for (uint32_t r = 0; r < W; ++r) {
+    Rank& rk = g->ranks[r];
+    HIP_TRY(hipSetDevice(rk.device));
+    for (uint32_t k = 1; k <= kmax; ++k)
+      OB_TRY(obnsl_score_all(rk.data, kind, ess, k, r, W, rk.tables[k - 1], 1));
+  }
+  return OBNSL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+obnsl_status obnsl_group_create(const uint8_t* codes, uint64_t num_rows, uint64_t col_stride,
+                                uint32_t num_vars, const uint32_t* cardinalities, const int* devices,
+                                uint32_t num_devices, obnsl_group** out) {
+  if (!out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  if (!devices || num_devices == 0 || num_devices > 64)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "a group needs between 1 and 64 devices");
+  auto g = std::make_unique<obnsl_group>();
+  g->n = num_vars;
+  g->N = num_rows;
+  g->ranks.resize(num_devices);
+  std::set<int> distinct;
+  for (uint32_t r = 0; r < num_devices; ++r) {
+    Rank& rk = g->ranks[r];
+    rk.device = devices[r];
+    distinct.insert(devices[r]);
+    OB_TRY(obnsl_data_create(codes, num_rows, col_stride, num_vars, cardinalities, devices[r], 0, &rk.data));
+    HIP_TRY(hipSetDevice(rk.device));
+    HIP_TRY(hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&rk.ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&rk.done, hipEventDisableTiming));
+    OB_TRY(obnsl_data_set_stream(rk.data, rk.stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rk.best), (size_t)num_vars * 3 * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rk.gathered), (size_t)num_devices * num_vars * 3 * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rk.combined), (size_t)num_vars * 3 * sizeof(double)));
+  }
+  const char* mode = std::getenv("OBNSL_GROUP_EXCHANGE");
+  const bool want_copy = mode && std::strcmp(mode, "copy") == 0;
+  const bool want_rccl = mode && std::strcmp(mode, "rccl") == 0;
+  const bool can_rccl = distinct.size() == num_devices;   // RCCL refuses a device listed twice
+  if (want_rccl && !can_rccl)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "OBNSL_GROUP_EXCHANGE=rccl needs every device of the group to be distinct");
+  if (!want_copy && can_rccl && (num_devices > 1 || want_rccl)) {
+    if (!rccl().ok()) return fail(OBNSL_ERR_RUNTIME, "librccl could not be opened for a multi-device group");
+    std::vector<nccl_comm_t> comms(num_devices, nullptr);
+    OB_TRY(nccl_check(rccl().CommInitAll(comms.data(), (int)num_devices, devices), "ncclCommInitAll"));
+    for (uint32_t r = 0; r < num_devices; ++r) g->ranks[r].comm = comms[r];
+    g->use_rccl = true;
+  } else {
+    // copy exchange between distinct devices reads a peer's memory
+    for (uint32_t r = 1; r < num_devices; ++r)
+      if (g->ranks[r].device != g->ranks[0].device) {
+        HIP_TRY(hipSetDevice(g->ranks[0].device));
+        (void)hipDeviceEnablePeerAccess(g->ranks[r].device, 0);   // already enabled is fine
+        HIP_TRY(hipSetDevice(g->ranks[r].device));
+        (void)hipDeviceEnablePeerAccess(g->ranks[0].device, 0);
+        (void)hipGetLastError();
+      }
+  }
+  *out = g.release();
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_group_destroy(obnsl_group* g) {
+  delete g;
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_group_info(const obnsl_group* g, uint32_t* num_devices, int* uses_rccl) {
+  if (!g) return fail(OBNSL_ERR_INVALID_ARGUMENT, "group is null");
+  if (num_devices) *num_devices = (uint32_t)g->ranks.size();
+  if (uses_rccl) *uses_rccl = g->use_rccl ? 1 : 0;
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_group_best_parents(obnsl_group* g, obnsl_score_kind kind, double ess,
+                                      uint32_t max_parents, int repack, double* best_score,
+                                      uint32_t* best_size, uint64_t* best_rank) {
+  if (!g || !best_score || !best_size || !best_rank) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (max_parents + 1 > g->n) return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
+  const uint32_t W = (uint32_t)g->ranks.size(), kmax = max_parents + 1;
+  OB_TRY(score_pass(g, kind, ess, kmax, repack));
+  std::vector<double*> send(W), recv(W);
+  for (uint32_t r = 0; r < W; ++r) {
+    Rank& rk = g->ranks[r];
+    HIP_TRY(hipSetDevice(rk.device));
+    OB_TRY(obnsl_best_parents_device(rk.data, rk.tables.data(), max_parents, rk.best));
+    send[r] = rk.best;
+    recv[r] = rk.gathered;
+  }
+  OB_TRY(all_gather_f64(g, send, recv, (uint64_t)g->n * 3));
+  for (uint32_t r = 0; r < W; ++r) {
+    Rank& rk = g->ranks[r];
+    HIP_TRY(hipSetDevice(rk.device));
+    OB_TRY(obnsl_combine_best_device(rk.data, rk.gathered, W, rk.combined));
+  }
+  // every rank holds the same combined record; read rank 0's, wait for all
+  std::vector<double> h((size_t)g->n * 3);
+  HIP_TRY(hipSetDevice(g->ranks[0].device));
+  HIP_TRY(hipMemcpyAsync(h.data(), g->ranks[0].combined, h.size() * sizeof(double), hipMemcpyDeviceToHost,
+                         g->ranks[0].stream));
+  for (uint32_t r = 0; r < W; ++r) {
+    HIP_TRY(hipSetDevice(g->ranks[r].device));
+    HIP_TRY(hipStreamSynchronize(g->ranks[r].stream));
+  }
+  for (uint32_t v = 0; v < g->n; ++v) {
+    best_score[v] = h[(size_t)v * 3];
+    best_size[v] = (uint32_t)h[(size_t)v * 3 + 1];
+    best_rank[v] = (uint64_t)h[(size_t)v * 3 + 2];
+  }
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_group_score_tables(obnsl_group* g, obnsl_score_kind kind, double ess,
+                                      uint32_t max_parents, int repack, double* const* tables_out) {
+  if (!g || !tables_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  if (max_parents + 1 > g->n) return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
+  const uint32_t W = (uint32_t)g->ranks.size(), kmax = max_parents + 1;
+  OB_TRY(score_pass(g, kind, ess, kmax, repack));
+  for (uint32_t k = 1; k <= kmax; ++k) {
+    std::vector<double*> ptr(W);
+    for (uint32_t r = 0; r < W; ++r) ptr[r] = g->ranks[r].tables[k - 1];
+    OB_TRY(all_reduce_max_f64(g, ptr, g->ranks[0].table_len[k - 1]));
+  }
+  Rank& r0 = g->ranks[0];
+  HIP_TRY(hipSetDevice(r0.device));
+  for (uint32_t k = 1; k <= kmax; ++k)
+    if (tables_out[k - 1])
+      HIP_TRY(hipMemcpyAsync(tables_out[k - 1], r0.tables[k - 1], r0.table_len[k - 1] * sizeof(double),
+                             hipMemcpyDeviceToHost, r0.stream));
+  for (uint32_t r = 0; r < W; ++r) {
+    HIP_TRY(hipSetDevice(g->ranks[r].device));
+    HIP_TRY(hipStreamSynchronize(g->ranks[r].stream));
+  }
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_group_exhaustive_search(obnsl_group* g, obnsl_score_kind kind, double ess,
+                                           uint32_t max_parents, uint64_t* parents_out,
+                                           double* total_score_out) {
+  if (!g || !parents_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  // reference: exhaustive_search.cpp:18-23
+  if (max_parents > g->n - 1) return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
+  if (g->n > 64) return fail(OBNSL_ERR_INVALID_ARGUMENT, "num_of_vars must be in [0, 64]");
+  const uint32_t W = (uint32_t)g->ranks.size(), kmax = max_parents + 1;
+  OB_TRY(score_pass(g, kind, ess, kmax, 0));
+  for (uint32_t k = 1; k <= kmax; ++k) {
+    std::vector<double*> ptr(W);
+    for (uint32_t r = 0; r < W; ++r) ptr[r] = g->ranks[r].tables[k - 1];
+    OB_TRY(all_reduce_max_f64(g, ptr, g->ranks[0].table_len[k - 1]));
+  }
+  // the subset dynamic program does not shard: rank 0 runs it on the whole tables
+  Rank& r0 = g->ranks[0];
+  HIP_TRY(hipSetDevice(r0.device));
+  obnsl_status st = obnsl_exhaustive_search_tables(r0.data, r0.tables.data(), max_parents, parents_out, total_score_out);
+  for (uint32_t r = 1; r < W; ++r) {
+    HIP_TRY(hipSetDevice(g->ranks[r].device));
+    HIP_TRY(hipStreamSynchronize(g->ranks[r].stream));
+  }
+  return st;
+}
+
+}  // extern "C"

@@ -60,6 +60,17 @@ SIGNATURES = {
     "obnsl_combine_best_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp]),
     "obnsl_exhaustive_search": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
                                                _u64p, _f64p]),
+    "obnsl_exhaustive_search_tables": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _u64p, _f64p]),
+    "obnsl_group_create": (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _u32p,
+                                          ctypes.POINTER(ctypes.c_int), ctypes.c_uint32, ctypes.POINTER(_vp)]),
+    "obnsl_group_destroy": (ctypes.c_int, [_vp]),
+    "obnsl_group_info": (ctypes.c_int, [_vp, _u32p, ctypes.POINTER(ctypes.c_int)]),
+    "obnsl_group_best_parents": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
+                                                ctypes.c_int, _f64p, _u32p, _u64p]),
+    "obnsl_group_score_tables": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
+                                                ctypes.c_int, ctypes.POINTER(_vp)]),
+    "obnsl_group_exhaustive_search": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
+                                                     _u64p, _f64p]),
     "obnsl_simulated_annealing": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
                                                  ctypes.c_uint64, ctypes.c_double, ctypes.c_double,
                                                  ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32,
@@ -379,3 +390,57 @@ class Data:
         n = ctypes.c_uint32(0)
         _check(lib.obnsl_kernel_time(self._h, k, ctypes.byref(ms), ctypes.byref(n), int(reset)))
         return ms.value, n.value
+
+
+class Group:
+    """Several GPUs behind one call (obnsl_group): `devices` lists the HIP device of
+    every rank; a device listed twice makes ranks share it (copy exchange)."""
+
+    def __init__(self, codes, card, devices):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        card = np.ascontiguousarray(card, dtype=np.uint32)
+        self.n, self.N, self.card = int(codes.shape[0]), int(codes.shape[1]), card
+        self.devices = [int(x) for x in devices]
+        dev = (ctypes.c_int * len(self.devices))(*self.devices)
+        self._h = _vp()
+        _check(lib.obnsl_group_create(codes.ctypes.data, self.N, self.N, self.n, card.ctypes.data_as(_u32p),
+                                      dev, len(self.devices), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib.obnsl_group_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        """(number of ranks, True when the exchanges go through RCCL)."""
+        w, r = ctypes.c_uint32(0), ctypes.c_int(0)
+        _check(lib.obnsl_group_info(self._h, ctypes.byref(w), ctypes.byref(r)))
+        return w.value, bool(r.value)
+
+    def best_parents(self, max_parents, kind=BDEU, ess=1.0, repack=False):
+        sc = np.zeros(self.n, dtype=np.float64)
+        sz = np.zeros(self.n, dtype=np.uint32)
+        rk = np.zeros(self.n, dtype=np.uint64)
+        _check(lib.obnsl_group_best_parents(self._h, kind, ess, max_parents, int(repack),
+                                            sc.ctypes.data_as(_f64p), sz.ctypes.data_as(_u32p),
+                                            rk.ctypes.data_as(_u64p)))
+        return sc, sz, rk
+
+    def score_tables(self, max_parents, kind=BDEU, ess=1.0, repack=False):
+        tabs = [np.zeros((binomial(self.n, k), k), dtype=np.float64) for k in range(1, max_parents + 2)]
+        arr = (_vp * len(tabs))(*[t.ctypes.data for t in tabs])
+        _check(lib.obnsl_group_score_tables(self._h, kind, ess, max_parents, int(repack), arr))
+        return tabs
+
+    def exhaustive_search(self, max_parents, kind=BDEU, ess=1.0):
+        masks = np.zeros(self.n, dtype=np.uint64)
+        total = ctypes.c_double(0.0)
+        _check(lib.obnsl_group_exhaustive_search(self._h, kind, ess, max_parents,
+                                                 masks.ctypes.data_as(_u64p), ctypes.byref(total)))
+        return [[j for j in range(self.n) if (int(m) >> j) & 1] for m in masks], total.value

@@ -118,8 +118,11 @@ struct PDAG {
 };
 
 // reference: include/structure_learning/exhaustive_search.h:17-20
+// `devices`: HIP devices to shard the scoring phase over (not in the reference,
+// which is single-device); empty = OPENBNSL_DEVICES if set, else the device the
+// DataframeWrapper lives on.
 PDAG exhaustive_search(const DataframeWrapper& df, const ScoreType& score_type,
-                       size_t max_parents, bool is_deterministic);
+                       size_t max_parents, bool is_deterministic, std::vector<int> devices = {});
 
 // reference: include/structure_learning/simulated_annealing.h:20-28
 PDAG simulated_annealing(const DataframeWrapper& df, const ScoreType& score_type,

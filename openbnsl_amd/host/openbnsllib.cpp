@@ -108,7 +108,7 @@ PYBIND11_MODULE(openbnsllib, m) {
   auto sl = m.def_submodule("structure_learning", "Structure learning submodule");
   sl.def("exhaustive_search", &exhaustive_search, "Run exhaustive search algorithm",
          py::arg("df"), py::arg("score_type"), py::arg("max_parents"),
-         py::arg("is_deterministic") = false);
+         py::arg("is_deterministic") = false, py::arg("devices") = std::vector<int>{});
   // reference: bindings/submodules/structure_learning.cpp:19-30 (same defaults)
   sl.def("simulated_annealing", &simulated_annealing, "Run simulated annealing algorithm",
          py::arg("df"), py::arg("score_type"), py::arg("max_parents"),

@@ -6,6 +6,8 @@
 
 #include "openbnsl_host.h"
 
+#include <cstdlib>
+
 namespace obnsl {
 
 obnsl_score_kind score_kind(const ScoreType& s) {
@@ -172,8 +174,27 @@ PDAG search_from_tables(size_t n, size_t max_parents,
   return g;
 }
 
+// Devices named by OPENBNSL_DEVICES ("0,1,2,3"): the group a search is sharded over
+// when the caller passes none.
+static std::vector<int> devices_from_env() {
+  std::vector<int> out;
+  const char* e = std::getenv("OPENBNSL_DEVICES");
+  if (!e) return out;
+  std::string cur;
+  for (const char* p = e;; ++p) {
+    if (*p == ',' || *p == '\0') {
+      if (!cur.empty()) out.push_back(std::atoi(cur.c_str()));
+      cur.clear();
+      if (*p == '\0') break;
+    } else if (*p != ' ') {
+      cur.push_back(*p);
+    }
+  }
+  return out;
+}
+
 PDAG exhaustive_search(const DataframeWrapper& df, const ScoreType& score_type,
-                       size_t max_parents, bool /*is_deterministic*/) {
+                       size_t max_parents, bool /*is_deterministic*/, std::vector<int> devices) {
   const size_t n = df.num_of_vars;
   // reference: exhaustive_search.cpp:18-23
   if (n == 0 || max_parents > n - 1)
@@ -187,9 +208,24 @@ PDAG exhaustive_search(const DataframeWrapper& df, const ScoreType& score_type,
   // being allocatable long before 64 variables (and its `1 << n` overflows from
   // 31); the engine refuses what the device cannot hold instead of failing in the
   // allocator.  search_from_tables() below is the same program on the host.
-  EngineData& eng = df.engine();
   std::vector<uint64_t> masks(n, 0);
-  {
+  if (devices.empty()) devices = devices_from_env();
+  if (devices.size() > 1) {
+    // several GPUs: the scoring phase sharded over a group (RCCL exchanges inside
+    // the engine), the dynamic program on the group's first device
+    std::vector<uint32_t> card(df.num_of_values.begin(), df.num_of_values.end());
+    obnsl_group* grp = nullptr;
+    py::gil_scoped_release nogil;
+    check(obnsl_group_create(df.codes.data(), df.num_of_datapoints, df.num_of_datapoints,
+                             static_cast<uint32_t>(n), card.data(), devices.data(),
+                             static_cast<uint32_t>(devices.size()), &grp));
+    const obnsl_status st = obnsl_group_exhaustive_search(grp, kind, score_ess(score_type),
+                                                          static_cast<uint32_t>(max_parents),
+                                                          masks.data(), nullptr);
+    obnsl_group_destroy(grp);
+    check(st);
+  } else {
+    EngineData& eng = df.engine();
     py::gil_scoped_release nogil;
     check(obnsl_exhaustive_search(eng.get(), kind, score_ess(score_type),
                                   static_cast<uint32_t>(max_parents), masks.data(), nullptr));

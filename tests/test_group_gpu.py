@@ -1,0 +1,99 @@
+"""GPU: several ranks behind ONE call (obnsl_group_*, include/obnsl_engine.h) --
+the host orchestration and both exchanges inside the engine library.  A box with
+one GPU lists its device several times: the ranks then share the GPU and
+exchange by device copies; a group of one rank with OBNSL_GROUP_EXCHANGE=rccl
+runs the same collectives through RCCL.  Results must equal the single-device
+calls bit for bit (same kernels on the same counts)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from openbnsl_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def data30():
+    cards = [2, 3, 4, 2, 3, 4, 3, 2, 4, 3, 2, 3, 4, 2, 3, 3, 2, 4, 2, 3, 4, 2, 3, 2, 4, 3, 2, 2, 3, 4]
+    codes, card, _, _ = synth.random_bn(cards, 6_000, seed=41)
+    return codes, card
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_group_best_parents_and_tables_equal_single_device(data30, world):
+    import torch
+    codes, card = data30
+    n, mp = codes.shape[0], 3
+    one = engine.Data(codes, card)
+    tabs = [one.score_all(k) for k in range(1, mp + 2)]
+    dev = [torch.from_numpy(t.reshape(-1)).cuda() for t in tabs]
+    want = one.best_parents([t.data_ptr() for t in dev], mp)
+    one.close()
+    g = engine.Group(codes, card, [0] * world)
+    assert g.info() == (world, False)             # a device listed twice: copy exchange
+    for repack in (False, True, False):           # cached plans, fresh bitmaps, cached counts
+        got = g.best_parents(mp, repack=repack)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    merged = g.score_tables(mp)
+    for a, b in zip(merged, tabs):
+        assert np.array_equal(a, b)               # every score present exactly once, none -inf
+    g.close()
+
+
+def test_group_search_equals_single_device_search():
+    codes, card, _, _ = synth.random_bn([2, 3, 4, 2, 3, 2, 4, 3, 2, 3, 2, 4, 3, 2], 20_000, seed=14)
+    d = engine.Data(codes, card)
+    want = d.exhaustive_search(3)
+    d.close()
+    g = engine.Group(codes, card, [0, 0, 0])
+    assert g.exhaustive_search(3) == want
+    with pytest.raises(ValueError, match=r"max_parents must be in \[0, num_of_vars-1\]"):
+        g.exhaustive_search(14)
+    g.close()
+
+
+def test_module_search_with_devices_argument():
+    """exhaustive_search(df, score, max_parents, devices=[...]) and OPENBNSL_DEVICES."""
+    import openbnsllib
+    from openbnsl_amd import graphs
+    codes, card, names = synth.asia(100_000, seed=0)
+    w = openbnsllib.base.DataframeWrapper(synth.to_dataframe(codes, names, labels=[["no", "yes"]] * 8))
+    one = openbnsllib.structure_learning.exhaustive_search(w, openbnsllib.score.BDeu(1.0), 3)
+    two = openbnsllib.structure_learning.exhaustive_search(w, openbnsllib.score.BDeu(1.0), 3, devices=[0, 0])
+    assert graphs.parent_lists(one) == graphs.parent_lists(two)
+    os.environ["OPENBNSL_DEVICES"] = "0, 0,0"
+    try:
+        env = openbnsllib.structure_learning.exhaustive_search(w, openbnsllib.score.BDeu(1.0), 3)
+    finally:
+        del os.environ["OPENBNSL_DEVICES"]
+    assert graphs.parent_lists(env) == graphs.parent_lists(one)
+
+
+def test_group_of_one_rank_through_rccl():
+    """The RCCL collectives themselves (ncclCommInitAll, grouped all-reduce and
+    all-gather from one thread) in a world of one rank: a fresh process, because the
+    exchange mode is read when the group is created."""
+    code = (
+        "import numpy as np, torch\n"
+        "from openbnsl_amd import engine, synth\n"
+        "codes, card, _, _ = synth.random_bn([2,3,4,2,3,4,3,2,4,3,2,3], 8000, seed=9)\n"
+        "d = engine.Data(codes, card)\n"
+        "tabs = [d.score_all(k) for k in (1, 2, 3)]\n"
+        "dev = [torch.from_numpy(t.reshape(-1)).cuda() for t in tabs]\n"
+        "want = d.best_parents([t.data_ptr() for t in dev], 2)\n"
+        "g = engine.Group(codes, card, [0])\n"
+        "assert g.info() == (1, True), g.info()\n"
+        "got = g.best_parents(2, repack=True)\n"
+        "assert all(np.array_equal(a, b) for a, b in zip(got, want))\n"
+        "assert all(np.array_equal(a, b) for a, b in zip(g.score_tables(2), tabs))\n"
+        "assert g.exhaustive_search(2) == d.exhaustive_search(2)\n"
+        "g.close(); d.close(); print('rccl group ok')\n")
+    env = dict(os.environ, OBNSL_GROUP_EXCHANGE="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "rccl group ok" in out.stdout, out.stdout + out.stderr
