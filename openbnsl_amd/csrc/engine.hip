@@ -417,33 +417,61 @@ __device__ __forceinline__ obnsl_v16f fp4_mfma(const obnsl_v8i a, const obnsl_v8
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, sc, 0, sc);
 }
 
-// One (rd, J) block: the A operand once, then per column block its B operand and
-// the instruction.  The scheduling fences keep the compiler from building the
-// operands of all four J up front (80 live registers, one wave per SIMD less).
-template <int JM, int J>
-__device__ __forceinline__ void mfma_block(const uint4 wa, const uint4 (&wb)[JM], obnsl_v16f (&acc)[JM]) {
-  const obnsl_v8i a = fp4_operand<J>(wa);
+// One (rd, J) block of a wave's NA x NB blocks: the NA A operands, then per
+// column block its B operand and NA instructions.  The scheduling fences keep
+// the compiler from building the operands of all four J up front (80 live
+// registers, one wave per SIMD less).
+template <int NA, int NB, int J>
+__device__ __forceinline__ void mfma_block(const uint4 (&wa)[NA], const uint4 (&wb)[NB],
+                                           obnsl_v16f (&acc)[NA][NB]) {
+  obnsl_v8i a[NA];
 #pragma unroll
-  for (int j = 0; j < JM; ++j) acc[j] = fp4_mfma<J>(a, fp4_operand<J>(wb[j]), acc[j]);
+  for (int i = 0; i < NA; ++i) a[i] = fp4_operand<J>(wa[i]);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const obnsl_v8i b = fp4_operand<J>(wb[j]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i][j] = fp4_mfma<J>(a[i], b, acc[i][j]);
+  }
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int JM>
+// One slab (KCW words per row) of a wave's NA x NB blocks: A rows arow + 32 i, B
+// rows brow + 32 j.  Operand cost is (NA + NB) builds per NA * NB instructions:
+// 1 x 4 (a wave per 32 rows, every column block: equal work for every wave when
+// the tile's last column blocks are empty) costs 6.25 vector instructions per
+// MFMA, 2 x 2 (full tiles) 5 -- which is what lets a wave that is alone on its
+// SIMD, while its neighbour stages or waits at the barrier, keep the matrix pipe fed.
+template <int NA, int NB>
 __device__ __forceinline__ void tile_mfma(const uint32_t* __restrict__ sA,
                                           const uint32_t* __restrict__ sB, uint32_t arow,
-                                          uint32_t brow, uint32_t hoff, obnsl_v16f (&acc)[JM]) {
+                                          uint32_t brow, uint32_t hoff, obnsl_v16f (&acc)[NA][NB]) {
+  // the words of round rd + 1 are read from LDS while round rd's instructions run
+  const uint32_t* pa = &sA[arow * LDS_STRIDE + hoff];
+  const uint32_t* pb = &sB[brow * LDS_STRIDE + hoff];
+  uint4 wa[NA], wb[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) wb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE);
 #pragma unroll 1
   for (int rd = 0; rd < KCW / 8; ++rd) {
-    const uint4 wa = *reinterpret_cast<const uint4*>(&sA[arow * LDS_STRIDE + rd * 8 + hoff]);
-    uint4 wb[JM];
+    // (the last round reads its own words again: one address computation for every round)
+    const int nx = min(rd + 1, KCW / 8 - 1) * 8;
+    uint4 na[NA], nb[NB];
 #pragma unroll
-    for (int j = 0; j < JM; ++j)
-      wb[j] = *reinterpret_cast<const uint4*>(&sB[(brow + 32 * j) * LDS_STRIDE + rd * 8 + hoff]);
+    for (int i = 0; i < NA; ++i) na[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) nb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE + nx);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_block<JM, 0>(wa, wb, acc);
-    mfma_block<JM, 1>(wa, wb, acc);
-    mfma_block<JM, 2>(wa, wb, acc);
-    mfma_block<JM, 3>(wa, wb, acc);
+    mfma_block<NA, NB, 0>(wa, wb, acc);
+    mfma_block<NA, NB, 1>(wa, wb, acc);
+    mfma_block<NA, NB, 2>(wa, wb, acc);
+    mfma_block<NA, NB, 3>(wa, wb, acc);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) wa[i] = na[i];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) wb[j] = nb[j];
   }
 }
 
@@ -453,7 +481,7 @@ constexpr uint32_t MFMA_MAX_STEPS = (1u << 24) / (KCW * 32);  // samples per wor
 // Everything after the tile is known, for one value of JM (a template
 // parameter of the whole loop nest, so that the accumulators live in the
 // accumulator registers from the first step to the epilogue).
-template <int KR, int KC, int JM>
+template <int KR, int KC, int NA, int NB>
 __device__ __forceinline__ void mfma_tile_body(
     uint32_t* __restrict__ smem, const uint32_t* __restrict__ planes, uint32_t wp,
     const RowDesc* __restrict__ rows, uint32_t nrows, const ColDesc* __restrict__ cols,
@@ -476,15 +504,21 @@ __device__ __forceinline__ void mfma_tile_body(
   }
   const uint32_t st_off = rl * LDS_STRIDE + q * 4;
 
-  // compute role: lane (lr, h) of wave wv holds row 32 wv + lr of A and column
-  // 32 j + lr of B, samples 128 h .. 128 h + 127 of each 256-sample round
+  // compute role: wave wv owns NA x NB blocks of 32 x 32 -- NA = 1: rows 32 wv ..,
+  // the tile's first NB column blocks; NA = NB = 2: the 64 x 64 quadrant (wv >> 1,
+  // wv & 1).  Lane (lr, h) holds row / column lr of each block, samples 128 h ..
+  // 128 h + 127 of each 256-sample round.
   const uint32_t lane = tid & 63, wv = tid >> 6;
   const uint32_t lr = lane & 31, h4 = (lane >> 5) * 4;
-  obnsl_v16f acc[JM];
+  const uint32_t wrow = NA == 1 ? wv * 32 : (wv >> 1) * 64;   // first row / column of the wave's blocks
+  const uint32_t wcol = NA == 1 ? 0 : (wv & 1) * 64;
+  obnsl_v16f acc[NA][NB];
 #pragma unroll
-  for (int j = 0; j < JM; ++j)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][j][i] = 0.0f;
   uint4 ga[NP][KR], gb[NP][KC];
 
   auto issue_loads = [&](uint32_t step) {
@@ -525,7 +559,7 @@ __device__ __forceinline__ void mfma_tile_body(
     if (more) issue_loads(step + 1);
     const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
     const uint32_t* sB = sA + TB * LDS_STRIDE;
-    tile_mfma<JM>(sA, sB, wv * 32 + lr, lr, h4, acc);
+    tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc);
     if (more) write_slab(buf ^ 1);
     __syncthreads();
   }
@@ -549,23 +583,25 @@ __device__ __forceinline__ void mfma_tile_body(
   __syncthreads();
   // C/D layout of the 32 x 32 forms: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const uint32_t rt = wv * 32 + (i & 3) + 8 * (i >> 2) + h4;
-    const uint32_t nc = s_nc[rt], M = s_M[rt];
-    const uint64_t base = s_base[rt];
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int j = 0; j < JM; ++j) {
-      const uint32_t c = col0 + 32 * j + lr;
-      if (c >= nc) continue;
-      const uint32_t v = (uint32_t)acc[j][i];
-      uint32_t* dst = counts + base + (uint64_t)c * M;
-      if (atomics) {
-        if (v) atomicAdd(dst, v);
-      } else {
-        *dst = v;
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t rt = wrow + 32 * a + (i & 3) + 8 * (i >> 2) + h4;
+      const uint32_t nc = s_nc[rt], M = s_M[rt];
+      const uint64_t base = s_base[rt];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const uint32_t c = col0 + wcol + 32 * j + lr;
+        if (c >= nc) continue;
+        const uint32_t v = (uint32_t)acc[a][j][i];
+        uint32_t* dst = counts + base + (uint64_t)c * M;
+        if (atomics) {
+          if (v) atomicAdd(dst, v);
+        } else {
+          *dst = v;
+        }
       }
     }
-  }
 }
 
 // A work unit of the matrix-core launch: one tile and a run of contraction
@@ -576,7 +612,7 @@ struct MfmaUnit {
 };
 
 template <int KR, int KC>
-__global__ __launch_bounds__(256) void bitgemm_mfma_kernel(
+__global__ __launch_bounds__(256, (KR + KC <= 5) ? 2 : 1) void bitgemm_mfma_kernel(
     const uint32_t* __restrict__ planes, uint32_t wp, const RowDesc* __restrict__ rows,
     uint32_t nrows, const ColDesc* __restrict__ cols, uint32_t ncols_total,
     const MfmaUnit* __restrict__ units, uint32_t* __restrict__ counts, int use_atomics) {
@@ -586,15 +622,18 @@ __global__ __launch_bounds__(256) void bitgemm_mfma_kernel(
   const uint32_t row0 = u.row_tile * MFMA_TILE, col0 = u.col_tile * MFMA_TILE;
   const uint32_t lim = rows[min(row0 + MFMA_TILE, nrows) - 1].ncols;  // the tile's last row has the most
   const uint32_t jm = (use_atomics & 2) ? 4u : lim > col0 ? min((lim - col0 + 31) / 32, 4u) : 1u;
-  const bool atomics = (use_atomics & 1) != 0;
-#define OBNSL_MFMA_BODY(JM)                                                                       \
-  mfma_tile_body<KR, KC, JM>(smem, planes, wp, rows, nrows, cols, ncols_total, row0, col0, counts, \
-                             u.step_lo, u.step_hi, atomics, (use_atomics & 4) != 0)
+  const bool atomics = (use_atomics & 1) != 0 && !(use_atomics & 8);
+#define OBNSL_MFMA_BODY(NA, NB)                                                                      \
+  mfma_tile_body<KR, KC, NA, NB>(smem, planes, wp, rows, nrows, cols, ncols_total, row0, col0, counts, \
+                                 u.step_lo, u.step_hi, atomics, (use_atomics & 4) != 0)
   switch (jm) {  // uniform over the workgroup
-    case 1: OBNSL_MFMA_BODY(1); break;
-    case 2: OBNSL_MFMA_BODY(2); break;
-    case 3: OBNSL_MFMA_BODY(3); break;
-    default: OBNSL_MFMA_BODY(4); break;
+    case 1: OBNSL_MFMA_BODY(1, 1); break;
+    case 2: OBNSL_MFMA_BODY(1, 2); break;
+    case 3: OBNSL_MFMA_BODY(1, 3); break;
+    default:
+      if (use_atomics & 16) OBNSL_MFMA_BODY(1, 4);   // OBNSL_NO_2X2 (comparison runs)
+      else OBNSL_MFMA_BODY(2, 2);
+      break;
   }
 #undef OBNSL_MFMA_BODY
 }
@@ -1473,7 +1512,11 @@ struct obnsl_data {
   std::vector<Plan*> lane_plans[2];                   // plans whose counts a lane is still producing
   // per ess: lgamma(ess / c) for c = 1..REDUCED_MAX_CELLS (index c), from the host's libm
   std::map<double, std::unique_ptr<DevBuf<double>>> lg_alpha;
-  hipStream_t count_stream() const { return count_lane >= 0 ? side[count_lane] : stream; }
+  hipStream_t count_stream() const {
+    // OBNSL_SERIAL: every launch on the main stream (profiling: kernels do not overlap)
+    static const bool serial = std::getenv("OBNSL_SERIAL") != nullptr;
+    return count_lane >= 0 && !serial ? side[count_lane] : stream;
+  }
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // around each bit-GEMM launch
   std::vector<uint32_t> ev_size;                      // subset size of each pending pair
   uint32_t ev_used = 0;                               // pending pairs
@@ -1830,14 +1873,17 @@ void launch_bitgemm(obnsl_data* d, const Plan* p, const Batch* b, uint32_t* coun
 obnsl_status build_units(Batch* b, uint32_t steps_total, uint32_t target) {
   if (b->units_steps == steps_total && b->units_target == target && b->nunits) return OBNSL_OK;
   uint64_t total = 0;
-  for (uint32_t blk : b->h_item_blocks) total += (uint64_t)blk * steps_total;
+  // a tile with fewer column blocks amortises its A operand over fewer instructions:
+  // measured 31 / 24 / 20 ns per instruction for 1 / 2 / 4 blocks, i.e. cost ~ 2 blocks + 1
+  auto weight = [](uint32_t blk) { return 2 * blk + 1; };
+  for (uint32_t blk : b->h_item_blocks) total += (uint64_t)weight(blk) * steps_total;
   const double per_unit = std::max(1.0, (double)total / (double)std::max(1u, target));
   std::vector<MfmaUnit> units;
   std::vector<std::pair<uint32_t, MfmaUnit>> tmp;  // (cost, unit)
   bool split = false;
   for (size_t i = 0; i < b->h_items.size(); ++i) {
     const uint32_t blk = b->h_item_blocks[i];
-    uint32_t ns = (uint32_t)std::max(1.0, std::floor((double)blk * steps_total / per_unit + 0.5));
+    uint32_t ns = (uint32_t)std::max(1.0, std::floor((double)weight(blk) * steps_total / per_unit + 0.5));
     ns = std::min(ns, std::max(1u, steps_total / 4));            // at least 4 steps per unit
     ns = std::max(ns, (steps_total + MFMA_MAX_STEPS - 1) / MFMA_MAX_STEPS);  // f32 counts stay exact
     ns = std::min(ns, steps_total);
@@ -1848,7 +1894,7 @@ obnsl_status build_units(Batch* b, uint32_t steps_total, uint32_t target) {
       u.col_tile = b->h_items[i].y;
       u.step_lo = (uint32_t)((uint64_t)steps_total * sidx / ns);
       u.step_hi = (uint32_t)((uint64_t)steps_total * (sidx + 1) / ns);
-      tmp.push_back({blk * (u.step_hi - u.step_lo), u});
+      tmp.push_back({weight(blk) * (u.step_hi - u.step_lo), u});
     }
   }
   std::stable_sort(tmp.begin(), tmp.end(),
@@ -1890,7 +1936,9 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   uint32_t sps = (steps_total + ksplit - 1) / ksplit;
   if (plan->mfma) sps = std::min(sps, MFMA_MAX_STEPS);  // f32 accumulators stay exact below 2^24
   ksplit = (steps_total + sps - 1) / sps;
-  static const int nojskip = (std::getenv("OBNSL_NO_JSKIP") ? 2 : 0) | (std::getenv("OBNSL_PROBE_NOLOAD") ? 4 : 0);
+  static const int nojskip = (std::getenv("OBNSL_NO_JSKIP") ? 2 : 0) | (std::getenv("OBNSL_PROBE_NOLOAD") ? 4 : 0) |
+                             (std::getenv("OBNSL_PROBE_NOATOMIC") ? 8 : 0) |
+                             (std::getenv("OBNSL_NO_2X2") ? 16 : 0);
   if (plan->mfma) {
     obnsl_status st = build_units(b, steps_total, std::max(want, b->nitems));
     if (st != OBNSL_OK) return st;
