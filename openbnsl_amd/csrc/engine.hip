@@ -6,23 +6,28 @@
 //
 // How this engine does it.  The uint8 data matrix is turned once into row
 // bitmaps: one N-bit plane per (variable, state).  A cell count of a joint
-// table is then popcount(AND of the cell's planes).  All tables of one subset
-// size k are produced by one "bit-GEMM": the k variables of a subset are split
-// into the kc smallest ("column side") and the kr = k - kc largest ("row side");
-// rows of the GEMM are the joint states of every kr-subset, columns the joint
-// states of every kc-subset, the contraction runs over the N rows of the data
-// in 32-row words, and C[row][col] = sum_w popc(A[row][w] & B[col][w]).  Only
+// table is then popcount(AND of the cell's planes), and all tables of one subset
+// size k are one GEMM-shaped contraction over the N rows of the data: the k
+// variables of a subset are split into the kc smallest ("column side") and the
+// kr = k - kc largest ("row side"); rows of the GEMM are the joint states of
+// every kr-subset, columns the joint states of every kc-subset, and
+// C[row][col] = sum over samples of A[row][sample] AND B[col][sample].  Only
 // combinations with max(column vars) < min(row vars) are computed (rows are
 // sorted by their smallest variable, so the valid region of each row tile is a
-// prefix of the column list).  This is integer AND/popcount work on the vector
-// ALU fed from LDS; there is no MFMA formulation worth having (one bit per
-// sample vs one byte per int8 MFMA operand).
+// prefix of the column list).  Only the joint states in which every variable is
+// in one of its states 1..r-1 are counted; the scorer recovers the others by
+// inclusion-exclusion from the tables of the sub-subsets.
 //
-// A workgroup owns a 128x128 tile of C, stages 32-word slabs of A and B through
-// LDS (the A/B rows are formed on the fly by ANDing the subset's planes) and
-// each thread keeps an 8x8 block of counters in registers.  Scores are then
-// evaluated from the dense counts by a second kernel, one wavefront per table,
-// in fp64.
+// The contraction runs on the matrix cores (bitgemm_mfma_kernel): a sample bit
+// becomes an FP4 nibble by masking, v_mfma_scale_f32_32x32x64_f8f6f4 multiplies
+// and adds 32 x 32 x 64 of them per instruction, and the f32 accumulators hold
+// exact integer counts.  A workgroup owns a 128 x 128 tile of C and stages
+// 32-word slabs of A and B through LDS (rows formed on the fly by ANDing the
+// subset's planes).  bitgemm_kernel is the same contraction as AND + popcount on
+// the vector ALU (OBNSL_GEMM=valu; 64 x 64 tiles).  Tables with many cells, and
+// subsets of more than 8 variables, are counted per row instead
+// (count_hist_kernel).  Scores come from one functional per table, G(S) - G(P),
+// evaluated in fp64 by score_reduced_kernel, two tables per wavefront.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1825,7 +1830,9 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     plan->h_col_before.resize(cgs.size());
     for (size_t g2 = 0; g2 < cgs.size(); ++g2) plan->h_col_before[g2] = cgs[g2].col_before;
     HIP_TRY(plan->rowoff.upload(rowoff));
-    HIP_TRY(plan->red.ensure(std::max<uint64_t>(plan->batches[0]->ncells, 1)));
+    // `red` itself is allocated where it is first counted into (ensure_counts, the
+    // sliced count of obnsl_precount_sharded): a sharded plan whose counts land in
+    // the whole plan's table never owns one
   }
   HIP_TRY(plan->cols.upload(cols));
   HIP_TRY(plan->cgs.upload(cgs));
@@ -2005,6 +2012,10 @@ obnsl_status ensure_counts(obnsl_data* d, Plan* plan) {
     if (plan->pending_lane >= 0) return join_lane(d, plan->pending_lane);
     return OBNSL_OK;
   }
+  if (!plan->red.p) {
+    HIP_TRY(plan->red.ensure(std::max<uint64_t>(plan->batches[0]->ncells, 1)));
+    plan->zeroed_epoch = 0;  // fresh memory: not cleared by any pack
+  }
   obnsl_status st = launch_count(d, plan, plan->batches[0].get(), plan->red.p,
                                  plan->zeroed_epoch == d->epoch);
   if (st != OBNSL_OK) return st;
@@ -2124,6 +2135,10 @@ obnsl_status run_hist_range(obnsl_data* d, uint32_t k, uint64_t lo, uint64_t hi,
     rpc = (rpc + HIST_ROWS_PER_ITER - 1) / HIST_ROWS_PER_ITER * HIST_ROWS_PER_ITER;
     nchunks = (d->N + rpc - 1) / rpc;
     const size_t lds = (size_t)std::min<uint32_t>(hb->max_cells, HIST_LDS_CELLS) * sizeof(uint32_t);
+    if (d->ev_used >= 4096) {  // bound the pool: fold what has been recorded so far
+      obnsl_status st = resolve_events(d);
+      if (st != OBNSL_OK) return st;
+    }
     if (d->ev_used == d->ev.size()) {
       hipEvent_t e0, e1;
       HIP_TRY(hipEventCreate(&e0));
@@ -2169,10 +2184,13 @@ obnsl_status choose_reduced(obnsl_data* d, uint32_t k, bool* use_reduced, uint64
   static const bool force_bits = std::getenv("OBNSL_FORCE_BITGEMM") != nullptr;
   bool use = allow_reduced && max_cells <= REDUCED_MAX_CELLS && !force_hist && k <= (uint32_t)KFAST;
   if (use && !force_bits) {
-    Plan* full = nullptr;
-    obnsl_status st = build_plan(d, k, 0, 1, true, &full);
-    if (st != OBNSL_OK) return st;
-    const double est_bit = (double)full->batches[0]->ncells * (double)d->wp * 6.7e-5;
+    // reduced cells of all size-k tables = e_k(r_1 - 1, ..., r_n - 1), the elementary
+    // symmetric polynomial of the reduced radices (no plan is built for an estimate)
+    std::vector<double> e(k + 1, 0.0);
+    e[0] = 1.0;
+    for (uint32_t v = 0; v < d->n; ++v)
+      for (uint32_t j = std::min(k, v + 1); j >= 1; --j) e[j] += e[j - 1] * (double)(d->card[v] - 1);
+    const double est_bit = e[k] * (double)d->wp * (use_mfma_gemm() ? 2.0e-5 : 6.7e-5);
     const double est_hist = (double)binom_host(d->n, k) * (double)d->N * 4.5e-4;
     if (est_hist < est_bit) use = false;
   }
@@ -2647,6 +2665,10 @@ obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_
       Batch* pb = part->batches[0].get();
       if (part->slice_off + pb->ncells > wb->ncells)
         return fail(OBNSL_ERR_RUNTIME, "internal: slice outside the count table");
+      if (!full->red.p) {
+        HIP_TRY(full->red.ensure(std::max<uint64_t>(wb->ncells, 1)));
+        full->zeroed_epoch = 0;
+      }
       if (full->zeroed_epoch != d->epoch)
         HIP_TRY(hipMemsetAsync(full->red.p, 0, wb->ncells * sizeof(uint32_t), d->stream));
       full->wants_zero = true;
