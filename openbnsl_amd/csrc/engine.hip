@@ -1918,6 +1918,19 @@ obnsl_status build_units(Batch* b, uint32_t steps_total, uint32_t target) {
   return OBNSL_OK;
 }
 
+// Units per matrix-core launch by number of tiles (OBNSL_WANT="a,b,c" overrides: tuning runs).
+uint32_t want_tier(int tier) {
+  static const std::vector<uint32_t> t = [] {
+    std::vector<uint32_t> v = {64u, 384u, 896u};
+    if (const char* e = std::getenv("OBNSL_WANT")) {
+      unsigned a = 0, b = 0, c = 0;
+      if (std::sscanf(e, "%u,%u,%u", &a, &b, &c) == 3 && a && b && c) v = {a, b, c};
+    }
+    return v;
+  }();
+  return t[tier];
+}
+
 // One bit-GEMM launch (timed with an event pair) filling `counts` for one batch.
 obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
                           bool prezeroed = false) {
@@ -1933,7 +1946,12 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   }();
   // the matrix-core kernel runs two 128 x 128 workgroups per CU: a few rounds of
   // 512 are enough, and every extra split adds the whole table in atomics
-  const uint32_t want = want_env ? want_env : plan->mfma ? 1024u : 8192u;
+  // (measured on the 37-variable workload, whole pass: one tile cut into ~64 units, 17
+  // tiles into ~384, 64 tiles into ~896 -- short units pay their prologue and epilogue,
+  // long ones leave CUs idle at the end of the launch)
+  const uint32_t want = want_env ? want_env
+                        : !plan->mfma ? 8192u
+                        : b->nitems <= 2 ? want_tier(0) : b->nitems <= 32 ? want_tier(1) : want_tier(2);
   static const uint32_t min_sps = [] {
     const char* e = std::getenv("OBNSL_MIN_SPS");
     return e ? std::max(1u, (uint32_t)std::atoi(e)) : 8u;
