@@ -1918,6 +1918,10 @@ obnsl_status build_units(Batch* b, uint32_t steps_total, uint32_t target) {
   return OBNSL_OK;
 }
 
+// A top size of at most this many tiles is counted whole on every rank rather
+// than in shards (one 128 x 128 matrix-core tile is sixteen 64 x 64 ones).
+uint64_t whole_below(const Plan* p) { return p->mfma ? 4 : 64; }
+
 // Units per matrix-core launch by number of tiles (OBNSL_WANT="a,b,c" overrides: tuning runs).
 uint32_t want_tier(int tier) {
   static const std::vector<uint32_t> t = [] {
@@ -2558,7 +2562,7 @@ obnsl_status obnsl_score_all(obnsl_data* d, obnsl_score_kind kind, double ess, u
           // a small top size is cheaper to count whole than to count twice
           st = build_plan(d, k, 0, 1, true, &full);
           if (st != OBNSL_OK) return st;
-          use = (full->total_items <= 64 || full->counted_epoch == d->epoch) ? full : own;
+          use = (full->total_items <= whole_below(full) || full->counted_epoch == d->epoch) ? full : own;
         }
       }
       st = ensure_counts(d, use);
@@ -2650,7 +2654,7 @@ obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_
   Plan* top = nullptr;
   st = build_plan(d, kmax, 0, 1, true, &top);
   if (st != OBNSL_OK) return st;
-  if (top_is_requested && num_shards > 1 && top->total_items > 64) {
+  if (top_is_requested && num_shards > 1 && top->total_items > whole_below(top)) {
     st = build_plan(d, kmax, shard, num_shards, true, &top);
     if (st != OBNSL_OK) return st;
   }
