@@ -1681,7 +1681,14 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
       for (uint64_t r = row0[lo]; r < row0[hi]; r += edge) {
         const uint64_t last = std::min<uint64_t>(r + edge, row0[hi]) - 1;
         while (row0[g + 1] <= last) ++g;
-        c += edge * (((uint64_t)ncols_below[rsub[g][0]] + cgroup - 1) / cgroup * cgroup);
+        const uint64_t lim = ncols_below[rsub[g][0]];
+        if (use_mfma_gemm()) {
+          // per column tile 2 x (column blocks) + 1, as build_units weighs them
+          const uint64_t rem = lim % edge;
+          c += (lim / edge) * 9 + (rem ? 2 * ((rem + cgroup - 1) / cgroup) + 1 : 0);
+        } else {
+          c += edge * ((lim + cgroup - 1) / cgroup * cgroup);
+        }
       }
       return c;
     };

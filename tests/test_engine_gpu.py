@@ -514,3 +514,33 @@ def test_subsets_larger_than_eight_variables(engine):
         np.maximum.at(best, oracle.enumerate_subsets(n, k).reshape(-1), t.reshape(-1))
     assert np.array_equal(sc, best)
     d.close()
+
+
+@pytest.mark.timeout(600)
+def test_counts_above_two_to_the_24_stay_exact(engine):
+    """The matrix-core kernel accumulates in f32, exact below 2^24 per workgroup;
+    the host cuts the contraction so that no workgroup sees more samples than that,
+    and the partial counts meet in uint32 counters.  17.8 million rows with cells
+    that hold more than 2^24 of them (one above 2^24 + 1, which f32 cannot hold)."""
+    import oracle
+    N = (1 << 24) + 1_000_003
+    rng = np.random.default_rng(24)
+    codes = np.empty((5, N), dtype=np.uint8)
+    codes[0] = (rng.random(N) < 0.9995).astype(np.uint8)        # state 1 almost always
+    codes[1] = (rng.random(N) < 0.9990).astype(np.uint8)
+    codes[2] = rng.integers(0, 3, size=N, dtype=np.uint8)
+    codes[3] = (rng.random(N) < 0.5).astype(np.uint8)
+    codes[4] = np.minimum(rng.integers(0, 40, size=N), 2).astype(np.uint8)  # state 2 for 95 % of the rows
+    card = np.array([2, 2, 3, 2, 3], dtype=np.uint32)
+    d = engine.Data(codes, card)
+    assert d.count_path(2) == "mfma"
+    red = d.reduced_table([0, 1])                               # the batch kernel's own counter
+    assert int(red[0, 0]) == int(np.count_nonzero((codes[0] == 1) & (codes[1] == 1))) > (1 << 24) + 1
+    for vs in ([0], [0, 1], [0, 1, 4], [0, 1, 2, 4], [0, 1, 2, 3, 4]):
+        want = oracle.count(codes, card, vs)
+        assert int(want.sum()) == N
+        assert np.array_equal(d.full_table_from_reduced(vs), want), vs
+        assert np.array_equal(d.count(vs), want), vs
+    for k in (1, 2, 3):
+        assert rel_err(d.score_all(k), oracle.score_all(codes, card, k, nthreads=8)) <= REL
+    d.close()
