@@ -491,7 +491,7 @@ __device__ __forceinline__ void mfma_tile_body(
     uint32_t* __restrict__ smem, const uint32_t* __restrict__ planes, uint32_t wp,
     const RowDesc* __restrict__ rows, uint32_t nrows, const ColDesc* __restrict__ cols,
     uint32_t ncols_total, uint32_t row0, uint32_t col0, uint32_t* __restrict__ counts,
-    uint32_t step_lo, uint32_t step_hi, bool atomics, bool probe_noload) {
+    uint32_t step_lo, uint32_t step_hi, bool atomics, bool probe_noload, bool probe_sameload = false) {
   constexpr int TB = MFMA_TILE;
   constexpr int NP = TB / 32;  // staging passes: 256 threads fill 32 slab rows per pass
   const uint32_t tid = threadIdx.x;
@@ -527,7 +527,7 @@ __device__ __forceinline__ void mfma_tile_body(
   uint4 ga[NP][KR], gb[NP][KC];
 
   auto issue_loads = [&](uint32_t step) {
-    const uint32_t w0 = step * KCW;
+    const uint32_t w0 = (probe_sameload ? step_lo : step) * KCW;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256, (KR + KC <= 5) ? 2 : 1) void bitgemm_mfma_kern
   const bool atomics = (use_atomics & 1) != 0 && !(use_atomics & 8);
 #define OBNSL_MFMA_BODY(NA, NB)                                                                      \
   mfma_tile_body<KR, KC, NA, NB>(smem, planes, wp, rows, nrows, cols, ncols_total, row0, col0, counts, \
-                                 u.step_lo, u.step_hi, atomics, (use_atomics & 4) != 0)
+                                 u.step_lo, u.step_hi, atomics, (use_atomics & 4) != 0, (use_atomics & 32) != 0)
   switch (jm) {  // uniform over the workgroup
     case 1: OBNSL_MFMA_BODY(1, 1); break;
     case 2: OBNSL_MFMA_BODY(1, 2); break;
@@ -1974,7 +1974,8 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   ksplit = (steps_total + sps - 1) / sps;
   static const int nojskip = (std::getenv("OBNSL_NO_JSKIP") ? 2 : 0) | (std::getenv("OBNSL_PROBE_NOLOAD") ? 4 : 0) |
                              (std::getenv("OBNSL_PROBE_NOATOMIC") ? 8 : 0) |
-                             (std::getenv("OBNSL_NO_2X2") ? 16 : 0);
+                             (std::getenv("OBNSL_NO_2X2") ? 16 : 0) |
+                             (std::getenv("OBNSL_PROBE_SAMELOAD") ? 32 : 0);
   if (plan->mfma) {
     obnsl_status st = build_units(b, steps_total, std::max(want, b->nitems));
     if (st != OBNSL_OK) return st;
