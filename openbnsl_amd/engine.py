@@ -365,6 +365,16 @@ class Data:
         parents = [[j for j in range(self.n) if (int(m) >> j) & 1] for m in masks]
         return parents, total.value
 
+    def exhaustive_search_tables(self, score_ptrs, max_parents):
+        """The subset dynamic program + back-track on device score tables (score_ptrs[k-1]:
+        device pointer of the size-k table).  Returns (parent lists, total score)."""
+        arr = (_vp * len(score_ptrs))(*score_ptrs)
+        masks = np.zeros(self.n, dtype=np.uint64)
+        total = ctypes.c_double(0.0)
+        _check(lib.obnsl_exhaustive_search_tables(self._h, arr, max_parents,
+                                                  masks.ctypes.data_as(_u64p), ctypes.byref(total)))
+        return [[j for j in range(self.n) if (int(m) >> j) & 1] for m in masks], total.value
+
     def simulated_annealing(self, max_parents, max_iters=10000, init_temp=1.0, cooling_rate=0.9995,
                             is_deterministic=False, seed=0, num_chains=0, kind=BDEU, ess=1.0):
         """(list of parent lists per node, total score) of the best graph found."""

@@ -57,6 +57,9 @@ def _load():
                                              ctypes.c_uint32, _u32p, ctypes.c_int,
                                              ctypes.c_double, ctypes.c_uint32, _u64p, _f64p]
     lib.oracle_exhaustive_search.restype = ctypes.c_int
+    lib.oracle_exhaustive_search_tables.argtypes = [ctypes.c_uint32, ctypes.c_uint32,
+                                                    ctypes.POINTER(ctypes.c_void_p), _u64p, _f64p]
+    lib.oracle_exhaustive_search_tables.restype = ctypes.c_int
     lib.oracle_max_threads.argtypes = []
     lib.oracle_max_threads.restype = ctypes.c_int
     return lib
@@ -139,6 +142,20 @@ def exhaustive_search(codes, card, max_parents, kind=BDEU, ess=1.0):
         raise RuntimeError(f"oracle_exhaustive_search failed: {rc}")
     parents = [[j for j in range(n) if (int(m) >> j) & 1] for m in masks]
     return parents, total.value
+
+
+def exhaustive_search_tables(n, max_parents, tables):
+    """The reference's dynamic program on given score tables: tables[k-1] is float64
+    [C(n,k), k] in visiting (colex) order.  Returns (parent lists, total score)."""
+    keep = [np.ascontiguousarray(t, dtype=np.float64) for t in tables]
+    arr = (ctypes.c_void_p * len(keep))(*[t.ctypes.data for t in keep])
+    masks = np.zeros(n, dtype=np.uint64)
+    total = ctypes.c_double(0.0)
+    rc = lib.oracle_exhaustive_search_tables(n, max_parents, arr, masks.ctypes.data_as(_u64p),
+                                             ctypes.byref(total))
+    if rc:
+        raise RuntimeError(f"oracle_exhaustive_search_tables failed: {rc}")
+    return [[j for j in range(n) if (int(m) >> j) & 1] for m in masks], total.value
 
 
 _ref_mod = None

@@ -250,10 +250,14 @@ int oracle_score_all(const uint8_t* data, uint64_t N, uint64_t stride, uint32_t 
  * parents_out[v] = bitmask of the parents of v in the returned graph.
  * Returns 0; -1 for max_parents > n-1 (:18-19); -2 for n > 64 (:22-23) and for
  * n too large for the n*2^n tables to be addressable here (n > 30). */
-int oracle_exhaustive_search(const uint8_t* data, uint64_t N, uint64_t stride,
-                             uint32_t n, const uint32_t* card, int kind, double ess,
-                             uint32_t max_parents, uint64_t* parents_out,
-                             double* total_score_out) {
+/* `tables` != NULL: the local scores are read from tables[k-1][idx * k + ci]
+ * (idx = position of the subset among the size-k subsets in the visiting order
+ * of :51-52,129, i.e. its colex rank) instead of being computed from the data;
+ * everything else -- visiting order, tie rules, back-track -- is the same loop. */
+static int search_impl(const uint8_t* data, uint64_t N, uint64_t stride,
+                       uint32_t n, const uint32_t* card, int kind, double ess,
+                       uint32_t max_parents, const double* const* tables,
+                       uint64_t* parents_out, double* total_score_out) {
   if (n == 0 || max_parents > n - 1) return -1;
   if (n > 30) return -2;
   const uint64_t combs = (uint64_t)1 << n;
@@ -263,7 +267,7 @@ int oracle_exhaustive_search(const uint8_t* data, uint64_t N, uint64_t stride,
   double* bls_score = (double*)malloc(sizeof(double) * n * combs);
   uint64_t* bls_ps = (uint64_t*)malloc(sizeof(uint64_t) * n * combs);
   uint64_t maxcells = 1;
-  { /* upper bound on table size: product of the max_varset largest cards */
+  if (!tables) { /* upper bound on table size: product of the max_varset largest cards */
     uint32_t tmp[64];
     memcpy(tmp, card, n * sizeof(uint32_t));
     for (uint32_t i = 0; i < max_varset && i < n; i++) {
@@ -288,10 +292,11 @@ int oracle_exhaustive_search(const uint8_t* data, uint64_t N, uint64_t stride,
   for (uint32_t size = 0; size <= n; size++) { /* :47 */
     const int calc_ls = size <= max_varset; /* :48 */
     uint64_t varset = size >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << size) - 1);
+    uint64_t idx = 0; /* position in the visiting order of this size */
     do {
       uint32_t vec[64], cards[64];
       const int k = oracle_combmask2vec(varset, vec);
-      if (calc_ls) { /* :55-57; the empty set gives the one-cell table {0:N} */
+      if (calc_ls && !tables) { /* :55-57; the empty set gives the one-cell table {0:N} */
         oracle_count(data, N, stride, card, vec, k, counts, maxcells);
         for (int i = 0; i < k; i++) cards[i] = card[vec[i]];
       }
@@ -301,7 +306,8 @@ int oracle_exhaustive_search(const uint8_t* data, uint64_t N, uint64_t stride,
         const uint32_t child = vec[ci];
         const uint64_t pmask = varset - ((uint64_t)1 << child);
         double ls = -INFINITY; /* :65 */
-        if (calc_ls) ls = oracle_local_score(counts, cards, k, ci, kind, ess, marg);
+        if (calc_ls && tables) ls = tables[k - 1][idx * (uint64_t)k + (uint64_t)ci];
+        else if (calc_ls) ls = oracle_local_score(counts, cards, k, ci, kind, ess, marg);
         double best_ls = ls; /* :75-87 */
         uint64_t best_ps = pmask;
         for (int pi = 0; pi < k; pi++) {
@@ -323,6 +329,7 @@ int oracle_exhaustive_search(const uint8_t* data, uint64_t N, uint64_t stride,
       }
       best_gs[varset] = bgs; /* :115-116 */
       best_ch[varset] = (uint8_t)bch;
+      idx++;
     } while (oracle_next_combmask(&varset, (int)n));
   }
 
@@ -342,6 +349,22 @@ int oracle_exhaustive_search(const uint8_t* data, uint64_t N, uint64_t stride,
   free(counts);
   free(marg);
   return 0;
+}
+
+int oracle_exhaustive_search(const uint8_t* data, uint64_t N, uint64_t stride,
+                             uint32_t n, const uint32_t* card, int kind, double ess,
+                             uint32_t max_parents, uint64_t* parents_out,
+                             double* total_score_out) {
+  return search_impl(data, N, stride, n, card, kind, ess, max_parents, NULL, parents_out,
+                     total_score_out);
+}
+
+/* The dynamic program and back-track of exhaustive_search.cpp:75-148 on given
+ * local scores (test input: tie-heavy tables pin the tie rules of :82 and :90-94). */
+int oracle_exhaustive_search_tables(uint32_t n, uint32_t max_parents, const double* const* tables,
+                                    uint64_t* parents_out, double* total_score_out) {
+  return search_impl(NULL, 0, 0, n, NULL, 0, 0.0, max_parents, tables, parents_out,
+                     total_score_out);
 }
 
 int oracle_max_threads(void) {
