@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 typedef int v8i __attribute__((ext_vector_type(8)));
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters, uint32
 }
 
 int loop_main();
+int loop2x2_main();
 int main() {
   const uint32_t words = 64;  // 2048 samples
   std::vector<uint32_t> A(32 * words), B(32 * words), want(32 * 32), have(32 * 32);
@@ -225,7 +227,7 @@ __device__ __forceinline__ pv8i p_raw(const uint4 w) {
   return f;
 }
 template <int VAR, int JM>
-__global__ __launch_bounds__(256) void loop_kernel(float* out, int steps) {
+__global__ __launch_bounds__(256) void loop_kernel(float* out, int steps, unsigned long long* stamps) {
   constexpr int STRIDE = 36;
   __shared__ __attribute__((aligned(16))) uint32_t smem[2 * 2 * 128 * STRIDE];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 31, h4 = (lane >> 5) * 4;
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(256) void loop_kernel(float* out, int steps) {
     for (int i = 0; i < 16; ++i) acc[j][i] = 0;
   const uint32_t* sA = smem;
   const uint32_t* sB = smem + 128 * STRIDE;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int s = 0; s < steps; ++s) {
 #pragma unroll 1
     for (int rd = 0; rd < 4; ++rd) {
@@ -260,6 +263,11 @@ __global__ __launch_bounds__(256) void loop_kernel(float* out, int steps) {
 #undef BLK
     }
   }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0) {
+    stamps[(blockIdx.x * 4 + wv) * 2] = c1 - c0;
+    stamps[(blockIdx.x * 4 + wv) * 2 + 1] = r1 - r0;
+  }
   float sum = 0;
   for (int j = 0; j < JM; ++j)
     for (int i = 0; i < 16; ++i) sum += acc[j][i];
@@ -271,18 +279,29 @@ void run_loop(float* dout, int blocks, const char* name) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  const int steps = 400;
+  const int steps = 4000;
+  static unsigned long long* dst = nullptr;
+  if (!dst) CHECK(hipMalloc(&dst, 4096 * 4 * 2 * 8));
   for (int rep = 0; rep < 2; ++rep) {
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((loop_kernel<VAR, JM>), dim3(blocks), dim3(256), 0, 0, dout, steps);
+    hipLaunchKernelGGL((loop_kernel<VAR, JM>), dim3(blocks), dim3(256), 0, 0, dout, steps, dst);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     if (rep == 1) {
       const double mfma_per_simd = (double)blocks * 4 * steps * 16 * JM / 1024.0;
-      std::printf("loop %-28s JM %d blocks %4d: %.3f ms, %.2f ns per MFMA per SIMD\n", name, JM, blocks, ms,
-                  ms * 1e6 / mfma_per_simd);
+      std::vector<unsigned long long> st((size_t)blocks * 8);
+      CHECK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<double> clk, cyc;
+      for (int w = 0; w < blocks * 4; ++w) {
+        clk.push_back((double)st[2 * w] / (double)st[2 * w + 1] * 0.1);          // GHz (realtime ticks at 100 MHz)
+        cyc.push_back((double)st[2 * w] / ((double)steps * 16 * JM));            // wave cycles per own MFMA
+      }
+      std::sort(clk.begin(), clk.end());
+      std::sort(cyc.begin(), cyc.end());
+      std::printf("loop %-28s JM %d blocks %4d: %.3f ms, %.2f ns per MFMA per SIMD; clock %.2f GHz, %.1f wave cycles per own MFMA\n",
+                  name, JM, blocks, ms, ms * 1e6 / mfma_per_simd, clk[clk.size() / 2], cyc[cyc.size() / 2]);
     }
   }
 }
@@ -296,6 +315,171 @@ int loop_main() {
     run_loop<2, 4>(dout, blocks, "no LDS reads, raw operands");
     run_loop<0, 1>(dout, blocks, "engine form");
     run_loop<0, 2>(dout, blocks, "engine form");
+  }
+  return loop2x2_main();
+}
+
+// ---- pipelined operand build: the operands of block j + 1 are built while the
+// MFMAs of block j issue (2 x 2 blocks per wave), scheduled explicitly.
+template <int J>
+__device__ __forceinline__ int p_scale() { return (J == 1) ? 0x7f7f7f7f : (J == 2) ? 0x7e7e7e7e : (int)0x80808080u; }
+
+struct Masks { uint32_t m0, m1, m2; };
+// the masks in scalar registers the compiler cannot see through: v_and_b32 with an SGPR
+// operand is a 4-byte instruction, with a 32-bit literal an 8-byte one
+__device__ __forceinline__ Masks opaque_masks() {
+  Masks m;
+  asm volatile("s_mov_b32 %0, 0x11111111\n\ts_mov_b32 %1, 0x22222222\n\ts_mov_b32 %2, 0x44444444"
+               : "=s"(m.m0), "=s"(m.m1), "=s"(m.m2));
+  return m;
+}
+template <int J>
+__device__ __forceinline__ pv8i p_operand_m(const uint4 w, const Masks& mk) {
+  pv8i f;
+  if constexpr (J < 3) {
+    const uint32_t m = J == 0 ? mk.m0 : J == 1 ? mk.m1 : mk.m2;
+    f[0] = (int)(w.x & m); f[1] = (int)(w.y & m); f[2] = (int)(w.z & m); f[3] = (int)(w.w & m);
+  } else {
+    f[0] = (int)((w.x >> 3) & mk.m0); f[1] = (int)((w.y >> 3) & mk.m0);
+    f[2] = (int)((w.z >> 3) & mk.m0); f[3] = (int)((w.w >> 3) & mk.m0);
+  }
+  f[4] = f[5] = f[6] = f[7] = 0;
+  return f;
+}
+static __device__ Masks g_mk_dummy;
+template <int J, bool OPAQUE = false>
+__device__ __forceinline__ void build2x2(const uint4 (&wa)[2], const uint4 (&wb)[2], pv8i (&a)[2], pv8i (&b)[2],
+                                         const Masks& mk = Masks{0x11111111u, 0x22222222u, 0x44444444u}) {
+  if constexpr (OPAQUE) {
+    a[0] = p_operand_m<J>(wa[0], mk); a[1] = p_operand_m<J>(wa[1], mk);
+    b[0] = p_operand_m<J>(wb[0], mk); b[1] = p_operand_m<J>(wb[1], mk);
+  } else {
+    a[0] = p_operand<J>(wa[0]); a[1] = p_operand<J>(wa[1]);
+    b[0] = p_operand<J>(wb[0]); b[1] = p_operand<J>(wb[1]);
+  }
+}
+template <int J>
+__device__ __forceinline__ void mfma2x2(const pv8i (&a)[2], const pv8i (&b)[2], v16f (&acc)[2][2]) {
+  constexpr int SC = (J == 1) ? 0x7f7f7f7f : (J == 2) ? 0x7e7e7e7e : (int)0x80808080u;
+  acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[0], acc[0][0], 4, 4, 0, SC, 0, SC);
+  acc[1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[0], acc[1][0], 4, 4, 0, SC, 0, SC);
+  acc[0][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[1], acc[0][1], 4, 4, 0, SC, 0, SC);
+  acc[1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[1], acc[1][1], 4, 4, 0, SC, 0, SC);
+}
+
+// MODE 0: 2 x 2, build-then-issue per block with fences (the engine's form);
+// MODE 1: software pipelined: build(j+1) interleaved with mfma(j) by sched_group_barrier.
+template <int MODE>
+__global__ __launch_bounds__(256) void loop2x2_kernel(float* out, int steps, unsigned long long* stamps) {
+  constexpr int STRIDE = 36;
+  __shared__ __attribute__((aligned(16))) uint32_t smem[2 * 2 * 128 * STRIDE];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 31, h4 = (lane >> 5) * 4;
+  for (uint32_t i = tid; i < 2 * 2 * 128 * STRIDE; i += 256) smem[i] = i * 2654435761u;
+  __syncthreads();
+  v16f acc[2][2];
+  for (int a = 0; a < 2; ++a)
+    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < 16; ++i) acc[a][j][i] = 0;
+  const uint32_t* pa = smem + ((wv >> 1) * 64 + lr) * STRIDE + h4;
+  const uint32_t* pb = smem + 128 * STRIDE + ((wv & 1) * 64 + lr) * STRIDE + h4;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  uint4 wa[2], wb[2];
+  for (int i = 0; i < 2; ++i) {
+    wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * STRIDE);
+    wb[i] = *reinterpret_cast<const uint4*>(pb + 32 * i * STRIDE);
+  }
+  pv8i oa[2], ob[2];
+  const Masks mk = opaque_masks();
+  constexpr bool OPQ = MODE >= 2;
+  if (MODE == 1 || MODE == 3) build2x2<0, OPQ>(wa, wb, oa, ob, mk);
+  for (int s = 0; s < steps; ++s) {
+#pragma unroll 1
+    for (int rd = 0; rd < 4; ++rd) {
+      const int nx = ((rd + 1) & 3) * 8;
+      uint4 na[2], nb[2];
+      for (int i = 0; i < 2; ++i) {
+        na[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * STRIDE + nx);
+        nb[i] = *reinterpret_cast<const uint4*>(pb + 32 * i * STRIDE + nx);
+      }
+      if (MODE == 0 || MODE == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        { pv8i a[2], b[2]; build2x2<0, OPQ>(wa, wb, a, b, mk); mfma2x2<0>(a, b, acc); __builtin_amdgcn_sched_barrier(0); }
+        { pv8i a[2], b[2]; build2x2<1, OPQ>(wa, wb, a, b, mk); mfma2x2<1>(a, b, acc); __builtin_amdgcn_sched_barrier(0); }
+        { pv8i a[2], b[2]; build2x2<2, OPQ>(wa, wb, a, b, mk); mfma2x2<2>(a, b, acc); __builtin_amdgcn_sched_barrier(0); }
+        { pv8i a[2], b[2]; build2x2<3, OPQ>(wa, wb, a, b, mk); mfma2x2<3>(a, b, acc); __builtin_amdgcn_sched_barrier(0); }
+      } else {
+        // block j: issue its 4 MFMAs (operands built one block earlier) with the 16-32 vector
+        // instructions of block j + 1's build spread between them
+        pv8i pa1[2], pb1[2];
+#define PIPE(J, JN, SRCA, SRCB)                                                  \
+        mfma2x2<J>(oa, ob, acc);                                                 \
+        build2x2<JN, OPQ>(SRCA, SRCB, pa1, pb1, mk);                             \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                          \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */        \
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); /* up to 8 VALU */  \
+        }                                                                        \
+        oa[0] = pa1[0]; oa[1] = pa1[1]; ob[0] = pb1[0]; ob[1] = pb1[1];
+        PIPE(0, 1, wa, wb)
+        PIPE(1, 2, wa, wb)
+        PIPE(2, 3, wa, wb)
+        PIPE(3, 0, na, nb)
+#undef PIPE
+      }
+      for (int i = 0; i < 2; ++i) { wa[i] = na[i]; wb[i] = nb[i]; }
+    }
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0) {
+    stamps[(blockIdx.x * 4 + wv) * 2] = c1 - c0;
+    stamps[(blockIdx.x * 4 + wv) * 2 + 1] = r1 - r0;
+  }
+  float sum = 0;
+  for (int a = 0; a < 2; ++a)
+    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < 16; ++i) sum += acc[a][j][i];
+  out[blockIdx.x * 256 + tid] = sum;
+}
+
+template <int MODE>
+void run_loop2x2(float* dout, int blocks, const char* name) {
+  const int steps = 4000;
+  static unsigned long long* dst = nullptr;
+  if (!dst) CHECK(hipMalloc(&dst, 4096 * 4 * 2 * 8));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((loop2x2_kernel<MODE>), dim3(blocks), dim3(256), 0, 0, dout, steps, dst);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep == 1) {
+      std::vector<unsigned long long> st((size_t)blocks * 8);
+      CHECK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<double> clk, cyc;
+      for (int w = 0; w < blocks * 4; ++w) {
+        clk.push_back((double)st[2 * w] / (double)st[2 * w + 1] * 0.1);
+        cyc.push_back((double)st[2 * w] / ((double)steps * 16 * 4));
+      }
+      std::sort(clk.begin(), clk.end());
+      std::sort(cyc.begin(), cyc.end());
+      const double mfma_per_simd = (double)blocks * 4 * steps * 16 * 4 / 1024.0;
+      std::printf("loop2x2 %-24s blocks %4d: %.3f ms, %.2f ns per MFMA per SIMD; clock %.2f GHz, %.1f wave cycles per own MFMA\n",
+                  name, blocks, ms, ms * 1e6 / mfma_per_simd, clk[clk.size() / 2], cyc[cyc.size() / 2]);
+    }
+  }
+}
+
+int loop2x2_main() {
+  float* dout;
+  CHECK(hipMalloc(&dout, 4096 * 256 * 4));
+  for (int blocks : {256, 512}) {
+    run_loop2x2<0>(dout, blocks, "build-then-issue");
+    run_loop2x2<1>(dout, blocks, "pipelined build");
+    run_loop2x2<2>(dout, blocks, "build-then-issue, sgpr masks");
+    run_loop2x2<3>(dout, blocks, "pipelined, sgpr masks");
   }
   return 0;
 }
