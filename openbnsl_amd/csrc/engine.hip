@@ -447,10 +447,11 @@ __device__ __forceinline__ void mfma_block(const uint4 (&wa)[NA], const uint4 (&
 // the tile's last column blocks are empty) costs 6.25 vector instructions per
 // MFMA, 2 x 2 (full tiles) 5 -- which is what lets a wave that is alone on its
 // SIMD, while its neighbour stages or waits at the barrier, keep the matrix pipe fed.
-template <int NA, int NB>
+template <int NA, int NB, class AfterRound>
 __device__ __forceinline__ void tile_mfma(const uint32_t* __restrict__ sA,
                                           const uint32_t* __restrict__ sB, uint32_t arow,
-                                          uint32_t brow, uint32_t hoff, obnsl_v16f (&acc)[NA][NB]) {
+                                          uint32_t brow, uint32_t hoff, obnsl_v16f (&acc)[NA][NB],
+                                          AfterRound after_round) {
   // the words of round rd + 1 are read from LDS while round rd's instructions run
   const uint32_t* pa = &sA[arow * LDS_STRIDE + hoff];
   const uint32_t* pb = &sB[brow * LDS_STRIDE + hoff];
@@ -473,6 +474,8 @@ __device__ __forceinline__ void tile_mfma(const uint32_t* __restrict__ sA,
     mfma_block<NA, NB, 1>(wa, wb, acc);
     mfma_block<NA, NB, 2>(wa, wb, acc);
     mfma_block<NA, NB, 3>(wa, wb, acc);
+    after_round(rd);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NA; ++i) wa[i] = na[i];
 #pragma unroll
@@ -480,43 +483,49 @@ __device__ __forceinline__ void tile_mfma(const uint32_t* __restrict__ sA,
   }
 }
 
-constexpr int MFMA_TILE = 128;        // tile edge of the matrix-core kernel
+constexpr int MFMA_TILE = 128;        // tile edge of the matrix-core kernel (256 for launches of many tiles)
+constexpr size_t BIG_TILE_FROM = 16384;  // 128 x 128 tiles from which a launch takes 256 x 256 tiles
 constexpr uint32_t MFMA_MAX_STEPS = (1u << 24) / (KCW * 32);  // samples per workgroup < 2^24
 
 // Everything after the tile is known, for one value of JM (a template
 // parameter of the whole loop nest, so that the accumulators live in the
 // accumulator registers from the first step to the epilogue).
-template <int KR, int KC, int NA, int NB>
+template <int KR, int KC, int NA, int NB, int TB>
 __device__ __forceinline__ void mfma_tile_body(
     uint32_t* __restrict__ smem, const uint32_t* __restrict__ planes, uint32_t wp,
     const RowDesc* __restrict__ rows, uint32_t nrows, const ColDesc* __restrict__ cols,
     uint32_t ncols_total, uint32_t row0, uint32_t col0, uint32_t* __restrict__ counts,
-    uint32_t step_lo, uint32_t step_hi, bool atomics, bool probe_noload, bool probe_sameload = false) {
-  constexpr int TB = MFMA_TILE;
-  constexpr int NP = TB / 32;  // staging passes: 256 threads fill 32 slab rows per pass
+    uint32_t step_lo, uint32_t step_hi, bool atomics, bool probe_noload, bool probe_sameload = false, int probe_x = 0) {
+  constexpr int PR = TB / 4;   // slab rows per staging pass: 2 TB threads, 8 per row
+  constexpr int NP = TB / PR;  // staging passes
+  static_assert(NP == KCW / 8, "one staging pass per round of the contraction step");
   const uint32_t tid = threadIdx.x;
-  // staging role: 8 threads cover one 32-word slab row with one uint4 each
+  // Staging role: 8 threads cover one 32-word slab row with one uint4 each, TB / 4 rows
+  // per pass.  The plane offsets of the tile's rows and columns sit in LDS behind
+  // the slabs (a pass is chosen by a loop counter: no register array to index).
   const uint32_t q = tid & 7, rl = tid >> 3;
-  uint32_t aoff[NP][KR], boff[NP][KC];
+  uint32_t* sAo = smem + 2 * 2 * TB * LDS_STRIDE;
+  uint32_t* sBo = sAo + TB * KR;
+  if (tid < (uint32_t)TB) {
+    const uint32_t r = min(row0 + tid, nrows - 1);
+    const uint32_t c = min(col0 + tid, ncols_total - 1);
 #pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const uint32_t r = min(row0 + rl + 32 * p, nrows - 1);
-    const uint32_t c = min(col0 + rl + 32 * p, ncols_total - 1);
+    for (int j = 0; j < KR; ++j) sAo[tid * KR + j] = rows[r].plane[j] * wp;
 #pragma unroll
-    for (int j = 0; j < KR; ++j) aoff[p][j] = rows[r].plane[j] * wp + q * 4;
-#pragma unroll
-    for (int j = 0; j < KC; ++j) boff[p][j] = cols[c].plane[j] * wp + q * 4;
+    for (int j = 0; j < KC; ++j) sBo[tid * KC + j] = cols[c].plane[j] * wp;
   }
   const uint32_t st_off = rl * LDS_STRIDE + q * 4;
 
-  // compute role: wave wv owns NA x NB blocks of 32 x 32 -- NA = 1: rows 32 wv ..,
-  // the tile's first NB column blocks; NA = NB = 2: the 64 x 64 quadrant (wv >> 1,
-  // wv & 1).  Lane (lr, h) holds row / column lr of each block, samples 128 h ..
+  // compute role: wave wv (of TB / 32) owns NA x NB blocks of 32 x 32 -- NA = 1: rows
+  // 32 wv .., the tile's first NB column blocks; NA = 2: rows 64 (wv >> 1) .., columns
+  // 32 NB (wv & 1) .. (a 64 x 64 quadrant of a 128 tile, a 64 x 128 eighth of a 256
+  // tile).  Lane (lr, h) holds row / column lr of each block, samples 128 h ..
   // 128 h + 127 of each 256-sample round.
+  static_assert(NA == 1 || 2 * 32 * NB == TB, "two waves side by side cover the tile's columns");
   const uint32_t lane = tid & 63, wv = tid >> 6;
   const uint32_t lr = lane & 31, h4 = (lane >> 5) * 4;
   const uint32_t wrow = NA == 1 ? wv * 32 : (wv >> 1) * 64;   // first row / column of the wave's blocks
-  const uint32_t wcol = NA == 1 ? 0 : (wv & 1) * 64;
+  const uint32_t wcol = NA == 1 ? 0 : (wv & 1) * (32 * NB);
   obnsl_v16f acc[NA][NB];
 #pragma unroll
   for (int a = 0; a < NA; ++a)
@@ -524,49 +533,106 @@ __device__ __forceinline__ void mfma_tile_body(
     for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][j][i] = 0.0f;
-  uint4 ga[NP][KR], gb[NP][KC];
 
-  auto issue_loads = [&](uint32_t step) {
-    const uint32_t w0 = (probe_sameload ? step_lo : step) * KCW;
+  __syncthreads();   // the offsets
+  if constexpr (TB == 128) {
+    // The whole next slab is loaded into registers at the start of a step and ANDed
+    // and stored into the other LDS buffer at its end.
+    uint4 ga[NP][KR], gb[NP][KC];
+    uint32_t aoff[NP][KR], boff[NP][KC];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
-      for (int j = 0; j < KR; ++j)
-        ga[p][j] = *reinterpret_cast<const uint4*>(planes + aoff[p][j] + w0);
+      for (int j = 0; j < KR; ++j) aoff[p][j] = sAo[(rl + PR * p) * KR + j] + q * 4;
 #pragma unroll
-      for (int j = 0; j < KC; ++j)
-        gb[p][j] = *reinterpret_cast<const uint4*>(planes + boff[p][j] + w0);
+      for (int j = 0; j < KC; ++j) boff[p][j] = sBo[(rl + PR * p) * KC + j] + q * 4;
     }
-  };
-  auto write_slab = [&](uint32_t buf) {
-    uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
-    uint32_t* sB = sA + TB * LDS_STRIDE;
+    auto issue_loads = [&](uint32_t step) {
+      const uint32_t w0 = (probe_sameload ? step_lo : step) * KCW;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      uint4 va = ga[p][0], vb = gb[p][0];
+      for (int p = 0; p < NP; ++p) {
 #pragma unroll
-      for (int j = 1; j < KR; ++j) va = and4(va, ga[p][j]);
+        for (int j = 0; j < KR; ++j) ga[p][j] = *reinterpret_cast<const uint4*>(planes + aoff[p][j] + w0);
 #pragma unroll
-      for (int j = 1; j < KC; ++j) vb = and4(vb, gb[p][j]);
-      *reinterpret_cast<uint4*>(&sA[st_off + 32 * p * LDS_STRIDE]) = va;
-      *reinterpret_cast<uint4*>(&sB[st_off + 32 * p * LDS_STRIDE]) = vb;
+        for (int j = 0; j < KC; ++j) gb[p][j] = *reinterpret_cast<const uint4*>(planes + boff[p][j] + w0);
+      }
+    };
+    auto write_slab = [&](uint32_t buf) {
+      uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
+      uint32_t* sB = sA + TB * LDS_STRIDE;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        uint4 va = ga[p][0], vb = gb[p][0];
+#pragma unroll
+        for (int j = 1; j < KR; ++j) va = and4(va, ga[p][j]);
+#pragma unroll
+        for (int j = 1; j < KC; ++j) vb = and4(vb, gb[p][j]);
+        *reinterpret_cast<uint4*>(&sA[st_off + PR * p * LDS_STRIDE]) = va;
+        *reinterpret_cast<uint4*>(&sB[st_off + PR * p * LDS_STRIDE]) = vb;
+      }
+    };
+    if (step_lo < step_hi) {
+      issue_loads(step_lo);
+      write_slab(0);
     }
-  };
-
-  if (step_lo < step_hi) {
-    issue_loads(step_lo);
-    write_slab(0);
-  }
-  __syncthreads();
-  for (uint32_t step = step_lo; step < step_hi; ++step) {
-    const uint32_t buf = (step - step_lo) & 1;
-    const bool more = step + 1 < step_hi && !probe_noload;
-    if (more) issue_loads(step + 1);
-    const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
-    const uint32_t* sB = sA + TB * LDS_STRIDE;
-    tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc);
-    if (more) write_slab(buf ^ 1);
     __syncthreads();
+    for (uint32_t step = step_lo; step < step_hi; ++step) {
+      const uint32_t buf = (step - step_lo) & 1;
+      const bool more = step + 1 < step_hi && !probe_noload;
+      if (more && !(probe_x & 2)) issue_loads(step + 1);
+      const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
+      const uint32_t* sB = sA + TB * LDS_STRIDE;
+      tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
+      if (more && !(probe_x & 1)) write_slab(buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    // One pass of the next slab is in flight at a time: its global loads are issued
+    // after a round's instructions, and ANDed and stored into the other LDS buffer
+    // after the next round's (16 staging registers instead of 64: what lets a wave
+    // hold 2 x 4 blocks of accumulators at two waves per SIMD).
+    uint4 ga[KR], gb[KC];
+    auto issue_pass = [&](uint32_t step, int p) {
+      const uint32_t w0 = (probe_sameload ? step_lo : step) * KCW + q * 4;
+      const uint32_t r = rl + PR * p;
+#pragma unroll
+      for (int j = 0; j < KR; ++j) ga[j] = *reinterpret_cast<const uint4*>(planes + sAo[r * KR + j] + w0);
+#pragma unroll
+      for (int j = 0; j < KC; ++j) gb[j] = *reinterpret_cast<const uint4*>(planes + sBo[r * KC + j] + w0);
+    };
+    auto write_pass = [&](uint32_t buf, int p) {
+      uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
+      uint32_t* sB = sA + TB * LDS_STRIDE;
+      uint4 va = ga[0], vb = gb[0];
+#pragma unroll
+      for (int j = 1; j < KR; ++j) va = and4(va, ga[j]);
+#pragma unroll
+      for (int j = 1; j < KC; ++j) vb = and4(vb, gb[j]);
+      *reinterpret_cast<uint4*>(&sA[st_off + PR * p * LDS_STRIDE]) = va;
+      *reinterpret_cast<uint4*>(&sB[st_off + PR * p * LDS_STRIDE]) = vb;
+    };
+    if (step_lo < step_hi) {
+#pragma unroll 1
+      for (int p = 0; p < NP; ++p) {
+        issue_pass(step_lo, p);
+        write_pass(0, p);
+      }
+    }
+    __syncthreads();
+    for (uint32_t step = step_lo; step < step_hi; ++step) {
+      const uint32_t buf = (step - step_lo) & 1;
+      const bool more = step + 1 < step_hi && !probe_noload;
+      if (more && !(probe_x & 2)) issue_pass(step + 1, 0);
+      const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
+      const uint32_t* sB = sA + TB * LDS_STRIDE;
+      tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [&](int rd) {
+        if (more) {
+          if (!(probe_x & 1)) write_pass(buf ^ 1, rd);
+          if (rd + 1 < NP && !(probe_x & 2)) issue_pass(step + 1, rd + 1);
+        }
+      });
+      __syncthreads();
+    }
   }
 
   // The slabs are dead now (the loop ends on a barrier): park the tile's row
@@ -616,28 +682,39 @@ struct MfmaUnit {
   uint32_t row_tile, col_tile, step_lo, step_hi;
 };
 
-template <int KR, int KC>
-__global__ __launch_bounds__(256, (KR + KC <= 5) ? 2 : 1) void bitgemm_mfma_kernel(
+// TB = 128: 4 waves, two workgroups per CU.  TB = 256: 8 waves, one workgroup per CU --
+// half the plane words fetched and three quarters of the operand builds and LDS reads
+// per instruction (a wave's full-tile share is 2 x 4 blocks), for launches of many tiles.
+template <int KR, int KC, int TB>
+__global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void bitgemm_mfma_kernel(
     const uint32_t* __restrict__ planes, uint32_t wp, const RowDesc* __restrict__ rows,
     uint32_t nrows, const ColDesc* __restrict__ cols, uint32_t ncols_total,
     const MfmaUnit* __restrict__ units, uint32_t* __restrict__ counts, int use_atomics) {
-  // two slabs of A and of B (one array: see bitgemm_kernel)
-  __shared__ __attribute__((aligned(16))) uint32_t smem[2 * 2 * MFMA_TILE * LDS_STRIDE];
+  // two slabs of A and of B (one array: see bitgemm_kernel), and behind them the
+  // plane offsets of the tile's rows and columns
+  __shared__ __attribute__((aligned(16))) uint32_t smem[2 * 2 * TB * LDS_STRIDE + TB * (KR + KC)];
   const MfmaUnit u = units[blockIdx.x];
-  const uint32_t row0 = u.row_tile * MFMA_TILE, col0 = u.col_tile * MFMA_TILE;
-  const uint32_t lim = rows[min(row0 + MFMA_TILE, nrows) - 1].ncols;  // the tile's last row has the most
-  const uint32_t jm = (use_atomics & 2) ? 4u : lim > col0 ? min((lim - col0 + 31) / 32, 4u) : 1u;
+  const uint32_t row0 = u.row_tile * TB, col0 = u.col_tile * TB;
+  const uint32_t lim = rows[min(row0 + TB, nrows) - 1].ncols;  // the tile's last row has the most
+  constexpr uint32_t JFULL = TB / 32;
+  const uint32_t jm = (use_atomics & 2) ? JFULL : lim > col0 ? min((lim - col0 + 31) / 32, JFULL) : 1u;
   const bool atomics = (use_atomics & 1) != 0 && !(use_atomics & 8);
-#define OBNSL_MFMA_BODY(NA, NB)                                                                      \
-  mfma_tile_body<KR, KC, NA, NB>(smem, planes, wp, rows, nrows, cols, ncols_total, row0, col0, counts, \
-                                 u.step_lo, u.step_hi, atomics, (use_atomics & 4) != 0, (use_atomics & 32) != 0)
+#define OBNSL_MFMA_BODY(NA, NB)                                                                          \
+  mfma_tile_body<KR, KC, NA, NB, TB>(smem, planes, wp, rows, nrows, cols, ncols_total, row0, col0, counts, \
+                                     u.step_lo, u.step_hi, atomics, (use_atomics & 4) != 0,              \
+                                     (use_atomics & 32) != 0, (use_atomics >> 6) & 3)
   switch (jm) {  // uniform over the workgroup
     case 1: OBNSL_MFMA_BODY(1, 1); break;
     case 2: OBNSL_MFMA_BODY(1, 2); break;
     case 3: OBNSL_MFMA_BODY(1, 3); break;
     default:
-      if (use_atomics & 16) OBNSL_MFMA_BODY(1, 4);   // OBNSL_NO_2X2 (comparison runs)
-      else OBNSL_MFMA_BODY(2, 2);
+      if constexpr (TB == 128) {
+        if (use_atomics & 16) OBNSL_MFMA_BODY(1, 4);   // OBNSL_NO_2X2 (comparison runs)
+        else OBNSL_MFMA_BODY(2, 2);
+      } else {
+        if (jm == 4) OBNSL_MFMA_BODY(1, 4);
+        else OBNSL_MFMA_BODY(2, 4);
+      }
       break;
   }
 #undef OBNSL_MFMA_BODY
@@ -1812,6 +1889,17 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     plan->mfma = use_mfma_gemm();
     plan->tile = plan->mfma ? MFMA_TILE : force_tile == 128 ? 128 : 64;
     make_tiles(plan->tile, tiles);
+    if (plan->mfma && (kr == 2 || (kr == 3 && kc == 2))) {
+      // launches of many tiles take 256 x 256 tiles
+      static const int big = [] {
+        const char* e = std::getenv("OBNSL_MFMA_TILE");
+        return e ? std::atoi(e) : 0;
+      }();
+      if (big == 256 || (big == 0 && tiles.size() >= BIG_TILE_FROM)) {
+        plan->tile = 256;
+        make_tiles(256, tiles);
+      }
+    }
     std::stable_sort(tiles.begin(), tiles.end(),
                      [](const std::pair<uint32_t, uint2>& a, const std::pair<uint32_t, uint2>& b) {
                        return a.first > b.first;
@@ -1866,8 +1954,13 @@ obnsl_status resolve_events(obnsl_data* d) {
 template <int KR, int KC>
 void launch_bitgemm(obnsl_data* d, const Plan* p, const Batch* b, uint32_t* counts, uint32_t grid,
                     uint32_t steps_total, uint32_t steps_per_split, int atomics) {
-  if (p->mfma)
-    hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC>), dim3(b->nunits), dim3(256), 0, d->count_stream(),
+  if (p->mfma && p->tile == 256) {
+    if constexpr (KR == 2 || (KR == 3 && KC == 2))
+      hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC, 256>), dim3(b->nunits), dim3(512), 0, d->count_stream(),
+                         d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
+                         b->units.p, counts, atomics);
+  } else if (p->mfma)
+    hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC, 128>), dim3(b->nunits), dim3(256), 0, d->count_stream(),
                        d->planes.p, d->wp, b->rows.p, b->nrows, p->cols.p, p->ncols_total,
                        b->units.p, counts, atomics);
   else if (p->tile == 128)
@@ -1975,7 +2068,8 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   static const int nojskip = (std::getenv("OBNSL_NO_JSKIP") ? 2 : 0) | (std::getenv("OBNSL_PROBE_NOLOAD") ? 4 : 0) |
                              (std::getenv("OBNSL_PROBE_NOATOMIC") ? 8 : 0) |
                              (std::getenv("OBNSL_NO_2X2") ? 16 : 0) |
-                             (std::getenv("OBNSL_PROBE_SAMELOAD") ? 32 : 0);
+                             (std::getenv("OBNSL_PROBE_SAMELOAD") ? 32 : 0) |
+                             (std::getenv("OBNSL_PROBE_NOWRITE") ? 64 : 0) | (std::getenv("OBNSL_PROBE_NOISSUE") ? 128 : 0);
   if (plan->mfma) {
     obnsl_status st = build_units(b, steps_total, std::max(want, b->nitems));
     if (st != OBNSL_OK) return st;

@@ -369,9 +369,10 @@ __device__ __forceinline__ void mfma2x2(const pv8i (&a)[2], const pv8i (&b)[2], 
 
 // MODE 0: 2 x 2, build-then-issue per block with fences (the engine's form);
 // MODE 1: software pipelined: build(j+1) interleaved with mfma(j) by sched_group_barrier.
-template <int MODE>
-__global__ __launch_bounds__(256) void loop2x2_kernel(float* out, int steps, unsigned long long* stamps) {
-  constexpr int STRIDE = 36;
+// KW: words per slab row (32: two workgroups per CU fit; 16: three or four); MINB: workgroups per CU asked for
+template <int MODE, int KW = 32, int MINB = 1>
+__global__ __launch_bounds__(256, MINB) void loop2x2_kernel(float* out, int steps, unsigned long long* stamps) {
+  constexpr int STRIDE = KW + 4;
   __shared__ __attribute__((aligned(16))) uint32_t smem[2 * 2 * 128 * STRIDE];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 31, h4 = (lane >> 5) * 4;
   for (uint32_t i = tid; i < 2 * 2 * 128 * STRIDE; i += 256) smem[i] = i * 2654435761u;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void loop2x2_kernel(float* out, int steps, uns
   for (int s = 0; s < steps; ++s) {
 #pragma unroll 1
     for (int rd = 0; rd < 4; ++rd) {
-      const int nx = ((rd + 1) & 3) * 8;
+      const int nx = ((rd + 1) & (KW / 8 - 1)) * 8;
       uint4 na[2], nb[2];
       for (int i = 0; i < 2; ++i) {
         na[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * STRIDE + nx);
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256) void loop2x2_kernel(float* out, int steps, uns
   out[blockIdx.x * 256 + tid] = sum;
 }
 
-template <int MODE>
+template <int MODE, int KW = 32, int MINB = 1>
 void run_loop2x2(float* dout, int blocks, const char* name) {
   const int steps = 4000;
   static unsigned long long* dst = nullptr;
@@ -450,7 +451,7 @@ void run_loop2x2(float* dout, int blocks, const char* name) {
   CHECK(hipEventCreate(&e1));
   for (int rep = 0; rep < 2; ++rep) {
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((loop2x2_kernel<MODE>), dim3(blocks), dim3(256), 0, 0, dout, steps, dst);
+    hipLaunchKernelGGL((loop2x2_kernel<MODE, KW, MINB>), dim3(blocks), dim3(256), 0, 0, dout, steps, dst);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -481,5 +482,9 @@ int loop2x2_main() {
     run_loop2x2<2>(dout, blocks, "build-then-issue, sgpr masks");
     run_loop2x2<3>(dout, blocks, "pipelined, sgpr masks");
   }
+  // three and four waves per SIMD (16-word slab rows: 40 KB of LDS per workgroup)
+  run_loop2x2<0, 16, 3>(dout, 768, "build-then-issue, 3/SIMD");
+  run_loop2x2<1, 16, 3>(dout, 768, "pipelined build, 3/SIMD");
+  run_loop2x2<0, 16, 4>(dout, 1024, "build-then-issue, 4/SIMD");
   return 0;
 }
