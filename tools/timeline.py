@@ -1,14 +1,22 @@
-"""Development helper: kernel timeline of the last bench step from a rocprofv3 kernel trace."""
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+"""Prints the kernel timeline of the last timed pass of a rocprofv3 --kernel-trace run
+(CSV): start offset from the pass's first kernel, duration, queue, kernel name.
+   python tools/timeline.py <dir with *_kernel_trace.csv> [first kernel substring]"""
+import csv
+import glob
+import sys
+
+d = sys.argv[1]
+first = sys.argv[2] if len(sys.argv) > 2 else "pack_planes"
+f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "pack_planes" in r["Kernel_Name"]]
-i0 = idx[-1]
-t0 = int(rows[i0]["Start_Timestamp"])
-for r in rows[i0:i0 + 40]:
-    nm = r["Kernel_Name"]
-    nm = nm.split("::")[-1][:44] if "::" in nm else nm[:44]
-    s = (int(r["Start_Timestamp"]) - t0) / 1e3
-    e = (int(r["End_Timestamp"]) - t0) / 1e3
-    print(f"{s:9.1f} {e:9.1f} us  q={r.get('Queue_Id','?')} grid={r.get('Grid_Size','?'):>8} {nm}")
+starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
+lo = starts[-1]
+t0 = int(rows[lo]["Start_Timestamp"])
+end = 0
+for r in rows[lo:]:
+    s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+    end = max(end, e)
+    name = r["Kernel_Name"].split("(")[0][-60:]
+    print(f"{s/1000:9.1f} us  +{(e-s)/1000:8.1f} us  q{r.get('Queue_Id','?'):>3}  {name}")
+print(f"pass: {end/1000:.1f} us")
