@@ -506,7 +506,7 @@ __device__ __forceinline__ void mfma_tile_body(
   const uint32_t q = tid & 7, rl = tid >> 3;
   uint32_t* sAo = smem + 2 * 2 * TB * LDS_STRIDE;
   uint32_t* sBo = sAo + TB * KR;
-  if (tid < (uint32_t)TB) {
+  if (TB != 128 && tid < (uint32_t)TB) {
     const uint32_t r = min(row0 + tid, nrows - 1);
     const uint32_t c = min(col0 + tid, ncols_total - 1);
 #pragma unroll
@@ -515,6 +515,14 @@ __device__ __forceinline__ void mfma_tile_body(
     for (int j = 0; j < KC; ++j) sBo[tid * KC + j] = cols[c].plane[j] * wp;
   }
   const uint32_t st_off = rl * LDS_STRIDE + q * 4;
+  // the epilogue's view of this thread's row (read now: no dependent load after the last step)
+  uint64_t e_base = 0;
+  uint32_t e_M = 0, e_nc = 0;   // 0 columns for a row past the end: nothing is written
+  if (tid < (uint32_t)TB && row0 + tid < nrows) {
+    e_base = rows[row0 + tid].out_base;
+    e_M = rows[row0 + tid].M;
+    e_nc = rows[row0 + tid].ncols;
+  }
 
   // compute role: wave wv (of TB / 32) owns NA x NB blocks of 32 x 32 -- NA = 1: rows
   // 32 wv .., the tile's first NB column blocks; NA = 2: rows 64 (wv >> 1) .., columns
@@ -534,18 +542,20 @@ __device__ __forceinline__ void mfma_tile_body(
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][j][i] = 0.0f;
 
-  __syncthreads();   // the offsets
   if constexpr (TB == 128) {
     // The whole next slab is loaded into registers at the start of a step and ANDed
-    // and stored into the other LDS buffer at its end.
+    // and stored into the other LDS buffer at its end (plane offsets in registers,
+    // straight from the descriptors: a short unit does not pay a trip through LDS).
     uint4 ga[NP][KR], gb[NP][KC];
     uint32_t aoff[NP][KR], boff[NP][KC];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
+      const uint32_t r = min(row0 + rl + PR * p, nrows - 1);
+      const uint32_t c = min(col0 + rl + PR * p, ncols_total - 1);
 #pragma unroll
-      for (int j = 0; j < KR; ++j) aoff[p][j] = sAo[(rl + PR * p) * KR + j] + q * 4;
+      for (int j = 0; j < KR; ++j) aoff[p][j] = rows[r].plane[j] * wp + q * 4;
 #pragma unroll
-      for (int j = 0; j < KC; ++j) boff[p][j] = sBo[(rl + PR * p) * KC + j] + q * 4;
+      for (int j = 0; j < KC; ++j) boff[p][j] = cols[c].plane[j] * wp + q * 4;
     }
     auto issue_loads = [&](uint32_t step) {
       const uint32_t w0 = (probe_sameload ? step_lo : step) * KCW;
@@ -587,6 +597,7 @@ __device__ __forceinline__ void mfma_tile_body(
       __syncthreads();
     }
   } else {
+    __syncthreads();   // the offsets
     // One pass of the next slab is in flight at a time: its global loads are issued
     // after a round's instructions, and ANDed and stored into the other LDS buffer
     // after the next round's (16 staging registers instead of 64: what lets a wave
@@ -636,20 +647,14 @@ __device__ __forceinline__ void mfma_tile_body(
   }
 
   // The slabs are dead now (the loop ends on a barrier): park the tile's row
-  // descriptors in LDS, one per thread, instead of 16 dependent global loads per lane.
+  // descriptors in LDS, one per thread, for the lanes that hold each row's counts.
   uint64_t* s_base = reinterpret_cast<uint64_t*>(smem);
   uint32_t* s_M = smem + 2 * TB;
   uint32_t* s_nc = smem + 3 * TB;
   if (tid < (uint32_t)TB) {
-    const uint32_t r = row0 + tid;
-    uint32_t nc = 0;
-    if (r < nrows) {
-      const RowDesc rd = rows[r];
-      s_base[tid] = rd.out_base;
-      s_M[tid] = rd.M;
-      nc = rd.ncols;
-    }
-    s_nc[tid] = nc;  // 0 for a row past the end: no column is valid
+    s_base[tid] = e_base;
+    s_M[tid] = e_M;
+    s_nc[tid] = e_nc;
   }
   __syncthreads();
   // C/D layout of the 32 x 32 forms: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
@@ -680,6 +685,7 @@ __device__ __forceinline__ void mfma_tile_body(
 // column blocks -- so that all workgroups of a launch take the same time.
 struct MfmaUnit {
   uint32_t row_tile, col_tile, step_lo, step_hi;
+  uint32_t blocks;   // 32-column blocks of the tile that hold a valid column (>= 1)
 };
 
 // TB = 128: 4 waves, two workgroups per CU.  TB = 256: 8 waves, one workgroup per CU --
@@ -692,12 +698,11 @@ __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void b
     const MfmaUnit* __restrict__ units, uint32_t* __restrict__ counts, int use_atomics) {
   // two slabs of A and of B (one array: see bitgemm_kernel), and behind them the
   // plane offsets of the tile's rows and columns
-  __shared__ __attribute__((aligned(16))) uint32_t smem[2 * 2 * TB * LDS_STRIDE + TB * (KR + KC)];
+  __shared__ __attribute__((aligned(16))) uint32_t smem[2 * 2 * TB * LDS_STRIDE + (TB == 128 ? 0 : TB * (KR + KC))];
   const MfmaUnit u = units[blockIdx.x];
   const uint32_t row0 = u.row_tile * TB, col0 = u.col_tile * TB;
-  const uint32_t lim = rows[min(row0 + TB, nrows) - 1].ncols;  // the tile's last row has the most
   constexpr uint32_t JFULL = TB / 32;
-  const uint32_t jm = (use_atomics & 2) ? JFULL : lim > col0 ? min((lim - col0 + 31) / 32, JFULL) : 1u;
+  const uint32_t jm = (use_atomics & 2) ? JFULL : u.blocks;
   const bool atomics = (use_atomics & 1) != 0 && !(use_atomics & 8);
 #define OBNSL_MFMA_BODY(NA, NB)                                                                          \
   mfma_tile_body<KR, KC, NA, NB, TB>(smem, planes, wp, rows, nrows, cols, ncols_total, row0, col0, counts, \
@@ -982,24 +987,26 @@ struct ReducedViews {
 // score i = G(S) - Gprev[rank(S without v_i)]; Gprev belongs to the next smaller
 // subset size (g0 for the empty set).  scores may be null (G only).
 // (templated on the subset size so that the per-variable loops unroll exactly)
-template <int KT>
+template <int KT, int PARTS>
 __global__ __launch_bounds__(64) void score_reduced_kernel(
     ReducedViews views, const RowGroupDesc* __restrict__ rgs, uint32_t nrgs,
     uint64_t ntables, uint32_t tables_per_wg, const uint32_t* __restrict__ card,
     const uint64_t* __restrict__ binom, uint32_t num_rows, int kind, double ess,
     double* __restrict__ G, const double* __restrict__ Gprev, double g0,
     double* __restrict__ scores, const double* __restrict__ lg_alpha, uint32_t e_stride) {
-  // The wavefront works on TWO tables at a time, one per half (32 lanes each):
+  // The wavefront works on PARTS tables at a time (2 or 4: 32 or 16 lanes each):
   // a table is a chain of dependent loads (descriptors -> table bases -> counts
-  // -> G of the subsets below), and two chains in flight per wave hide more of
-  // that latency than one.  Both halves pass the same barriers; a half without a
-  // table (odd count) idles through them.
+  // -> G of the subsets below), and several chains in flight per wave hide more
+  // of that latency than one; four pay when the tables are small (few cells per
+  // lane either way).  All parts pass the same barriers; a part without a table
+  // idles through them.
+  constexpr uint32_t SC_PARTS = PARTS, SC_LANES = 64 / PARTS;
   extern __shared__ __attribute__((aligned(16))) uint32_t E_all[];
   __shared__ SizeView sv[KFAST + 1];
-  __shared__ uint32_t s_vars[2][KFAST], s_cards[2][KFAST];
-  __shared__ uint64_t pat_base_all[2][1 << KT];  // first counter of the reduced table of a support pattern
+  __shared__ uint32_t s_vars[SC_PARTS][KFAST], s_cards[SC_PARTS][KFAST];
+  __shared__ uint64_t pat_base_all[SC_PARTS][1 << KT];  // first counter of the reduced table of a support pattern
   constexpr uint32_t k = KT;
-  const uint32_t half = threadIdx.x >> 5, lane = threadIdx.x & 31;
+  const uint32_t half = threadIdx.x / SC_LANES, lane = threadIdx.x % SC_LANES;
   uint32_t* E = E_all + (size_t)half * e_stride;
   uint64_t* pat_base = pat_base_all[half];
 #pragma unroll
@@ -1020,7 +1027,7 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
   __syncthreads();
   const ColGroupDesc* __restrict__ own_cgs = sv[k].cgs;
 
-  for (uint64_t tp = t0; tp < t1; tp += 2) {
+  for (uint64_t tp = t0; tp < t1; tp += SC_PARTS) {
     const uint64_t t = tp + half;
     const bool active = t < t1;
     uint32_t vars[KFAST], cards[KFAST];
@@ -1055,7 +1062,7 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
       }
       // where the reduced table of each non-empty support pattern starts: the table
       // of T (|T| = j) lives in size j's layout, row side = its kr_j largest variables
-      for (uint32_t pat = lane + 1; pat < (1u << k); pat += 32) {
+      for (uint32_t pat = lane + 1; pat < (1u << k); pat += SC_LANES) {
         const SizeView s = sv[__popc(pat)];
         uint64_t colrank = 0, rowrank = 0;
         uint32_t mred = 1, p = 0;
@@ -1078,7 +1085,7 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
     // E(e): digit 0 = "any".  Within a pattern the counter index is the mixed-radix
     // number of the non-zero digits (radix r - 1, first variable most significant).
     if (active) {
-      for (uint32_t cell = lane; cell < cells; cell += 32) {
+      for (uint32_t cell = lane; cell < cells; cell += SC_LANES) {
         uint32_t rem = cell, pat = 0, key = 0, mul = 1;
 #pragma unroll
         for (int i = KFAST - 1; i >= 0; --i) {
@@ -1104,7 +1111,7 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
         const uint32_t r = cards[i];
         const uint32_t lines = fast_div(cells, inv_card[i]);
         const float inv_w = 1.0f / (float)w;
-        for (uint32_t l = lane; l < lines; l += 32) {
+        for (uint32_t l = lane; l < lines; l += SC_LANES) {
           const uint32_t h = fast_div(l, inv_w), lo_ = l - h * w;
           const uint32_t base = h * (r * w) + lo_;
           uint32_t sum = 0;
@@ -1121,19 +1128,19 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
       if (kind == OBNSL_SCORE_BDEU) {
         const double a = ess / (double)cells;
         const double lg_a = lg_alpha[cells];  // lgamma(a): the same for every table of this size
-        for (uint32_t c = lane; c < cells; c += 32) {
+        for (uint32_t c = lane; c < cells; c += SC_LANES) {
           const uint32_t nc = E[c];
           if (nc) gsum += lgamma_pos((double)nc + a) - lg_a;
         }
       } else {
-        for (uint32_t c = lane; c < cells; c += 32) {
+        for (uint32_t c = lane; c < cells; c += SC_LANES) {
           const uint32_t nc = E[c];
           if (nc) gsum += (double)nc * log((double)nc);
         }
       }
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o);  // within the half
+    for (int o = SC_LANES / 2; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o);  // within the part
     if (active && lane == 0) G[rank] = gsum;
     if (scores != nullptr) {
 #pragma unroll
@@ -1591,6 +1598,7 @@ struct obnsl_data {
   hipStream_t side[2] = {nullptr, nullptr};
   hipEvent_t side_fork = nullptr, side_join[2] = {nullptr, nullptr};
   int count_lane = -1;                                // launch_count targets side[count_lane] (-1: `stream`)
+  bool beside_large = false;                          // the launches of obnsl_precount run beside one of many tiles
   std::vector<Plan*> lane_plans[2];                   // plans whose counts a lane is still producing
   // per ess: lgamma(ess / c) for c = 1..REDUCED_MAX_CELLS (index c), from the host's libm
   std::map<double, std::unique_ptr<DevBuf<double>>> lg_alpha;
@@ -2001,6 +2009,7 @@ obnsl_status build_units(Batch* b, uint32_t steps_total, uint32_t target) {
       u.col_tile = b->h_items[i].y;
       u.step_lo = (uint32_t)((uint64_t)steps_total * sidx / ns);
       u.step_hi = (uint32_t)((uint64_t)steps_total * (sidx + 1) / ns);
+      u.blocks = blk;
       tmp.push_back({weight(blk) * (u.step_hi - u.step_lo), u});
     }
   }
@@ -2050,12 +2059,15 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   }();
   // the matrix-core kernel runs two 128 x 128 workgroups per CU: a few rounds of
   // 512 are enough, and every extra split adds the whole table in atomics
-  // (measured on the 37-variable workload, whole pass: one tile cut into ~64 units, 17
-  // tiles into ~384, 64 tiles into ~896 -- short units pay their prologue and epilogue,
-  // long ones leave CUs idle at the end of the launch)
+  // (measured on the 37-variable workload, whole pass: one tile cut into ~64 units -- 16
+  // units of ~64 steps when it runs beside a launch of many tiles, whose workgroup slots
+  // it would take --, 17 tiles into ~384, 64 tiles into ~896: short units pay their
+  // prologue and epilogue, long ones leave CUs idle at the end of the launch)
   const uint32_t want = want_env ? want_env
                         : !plan->mfma ? 8192u
-                        : b->nitems <= 2 ? want_tier(0) : b->nitems <= 32 ? want_tier(1) : want_tier(2);
+                        : b->nitems <= 2 ? (d->beside_large ? std::min(want_tier(0), std::max(16u, steps_total / 64))
+                                                            : want_tier(0))
+                        : b->nitems <= 32 ? want_tier(1) : want_tier(2);
   static const uint32_t min_sps = [] {
     const char* e = std::getenv("OBNSL_MIN_SPS");
     return e ? std::max(1u, (uint32_t)std::atoi(e)) : 8u;
@@ -2174,14 +2186,22 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
     }();
     uint32_t tpw = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(2, b->ntables / 2048));
     if (tpw_env) tpw = tpw_env;
-    tpw = (tpw + 1) & ~1u;  // a wavefront takes its tables two at a time
+    // four tables per wavefront when the tables are small (full tables of at most 256
+    // cells, 32 counted cells per table on average), else two
+    const uint32_t parts = (max_cells <= 256 && b->ncells <= 32 * b->ntables) ? 4 : 2;
+    tpw = (tpw + parts - 1) / parts * parts;  // a wavefront takes its tables `parts` at a time
     const uint32_t grid = (uint32_t)((b->ntables + tpw - 1) / tpw);
     const uint32_t e_stride = (uint32_t)((max_cells + 3) & ~3ull);
-#define OBNSL_LAUNCH_SCORER(KT)                                                                  \
-  hipLaunchKernelGGL((score_reduced_kernel<KT>), dim3(grid), dim3(64),                           \
-                     (size_t)2 * e_stride * sizeof(uint32_t), d->stream, views, b->rgs.p,        \
+#define OBNSL_LAUNCH_SCORER_P(KT, P)                                                             \
+  hipLaunchKernelGGL((score_reduced_kernel<KT, P>), dim3(grid), dim3(64),                        \
+                     (size_t)P * e_stride * sizeof(uint32_t), d->stream, views, b->rgs.p,        \
                      b->nrgs, b->ntables, tpw, d->d_card.p, d->d_binom.p, (uint32_t)d->N,        \
                      (int)kind, ess, plan->G.p, gprev, g0, scores, lg_alpha, e_stride)
+#define OBNSL_LAUNCH_SCORER(KT)            \
+  do {                                     \
+    if (parts == 4) OBNSL_LAUNCH_SCORER_P(KT, 4); \
+    else OBNSL_LAUNCH_SCORER_P(KT, 2);     \
+  } while (0)
     switch (k) {
       case 1: OBNSL_LAUNCH_SCORER(1); break;
       case 2: OBNSL_LAUNCH_SCORER(2); break;
@@ -2192,6 +2212,7 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
       case 7: OBNSL_LAUNCH_SCORER(7); break;
       default: OBNSL_LAUNCH_SCORER(8); break;
     }
+#undef OBNSL_LAUNCH_SCORER_P
 #undef OBNSL_LAUNCH_SCORER
     HIP_TRY(hipGetLastError());
   }
@@ -2762,6 +2783,11 @@ obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_
   }
   // fork: the lanes start after everything queued so far (the pack)
   HIP_TRY(hipEventRecord(d->side_fork, d->stream));
+  struct BesideLarge {   // holds for the launches queued by this call only
+    obnsl_data* d;
+    ~BesideLarge() { d->beside_large = false; }
+  } beside_guard{d};
+  d->beside_large = top->total_items > 32 && top->counted_epoch != d->epoch;
   if (top->counted_epoch != d->epoch) {
     HIP_TRY(hipStreamWaitEvent(d->side[0], d->side_fork, 0));
     d->count_lane = 0;

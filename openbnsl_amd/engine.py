@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libobnsl_engine.so")
+# OBNSL_ENGINE_LIB: another build of the same library (A/B timing of kernel versions)
+LIB_PATH = os.environ.get("OBNSL_ENGINE_LIB") or os.path.join(_HERE, "lib", "libobnsl_engine.so")
 
 BDEU, K2, BIC, AIC = 0, 1, 2, 3
 MAX_SUBSET = 32
