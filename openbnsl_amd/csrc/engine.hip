@@ -484,6 +484,7 @@ __device__ __forceinline__ void tile_mfma(const uint32_t* __restrict__ sA,
 }
 
 constexpr int MFMA_TILE = 128;        // tile edge of the matrix-core kernel (256 for launches of many tiles)
+constexpr uint64_t IMAGE_MAX_BYTES = 64ull << 20;  // tile images of one split launch (1024 tiles)
 constexpr size_t BIG_TILE_FROM = 16384;  // 128 x 128 tiles from which a launch takes 256 x 256 tiles
 constexpr uint32_t MFMA_MAX_STEPS = (1u << 24) / (KCW * 32);  // samples per workgroup < 2^24
 
@@ -495,7 +496,8 @@ __device__ __forceinline__ void mfma_tile_body(
     uint32_t* __restrict__ smem, const uint32_t* __restrict__ planes, uint32_t wp,
     const RowDesc* __restrict__ rows, uint32_t nrows, const ColDesc* __restrict__ cols,
     uint32_t ncols_total, uint32_t row0, uint32_t col0, uint32_t* __restrict__ counts,
-    uint32_t step_lo, uint32_t step_hi, bool atomics, bool probe_noload, bool probe_sameload = false, int probe_x = 0) {
+    uint32_t step_lo, uint32_t step_hi, bool atomics, uint32_t* __restrict__ image, bool probe_noload,
+    bool probe_sameload = false, int probe_x = 0) {
   constexpr int PR = TB / 4;   // slab rows per staging pass: 2 TB threads, 8 per row
   constexpr int NP = TB / PR;  // staging passes
   static_assert(NP == KCW / 8, "one staging pass per round of the contraction step");
@@ -646,6 +648,25 @@ __device__ __forceinline__ void mfma_tile_body(
     }
   }
 
+  // A tile whose contraction is cut into several units adds its partial counts into
+  // a row-major TB x TB image of the tile (32 neighbouring columns of a row per
+  // half-wave and instruction: whole cache lines per atomic request, where the count
+  // table itself would be hit at a stride of M cells); image_scatter_kernel moves
+  // the finished images into the table.
+  if (image != nullptr) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t rt = wrow + 32 * a + (i & 3) + 8 * (i >> 2) + h4;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const uint32_t v = (uint32_t)acc[a][j][i];
+          if (v && !(probe_x & 4)) atomicAdd(image + rt * TB + wcol + 32 * j + lr, v);
+        }
+      }
+    return;
+  }
   // The slabs are dead now (the loop ends on a barrier): park the tile's row
   // descriptors in LDS, one per thread, for the lanes that hold each row's counts.
   uint64_t* s_base = reinterpret_cast<uint64_t*>(smem);
@@ -670,6 +691,7 @@ __device__ __forceinline__ void mfma_tile_body(
         const uint32_t c = col0 + wcol + 32 * j + lr;
         if (c >= nc) continue;
         const uint32_t v = (uint32_t)acc[a][j][i];
+        if ((probe_x & 4) && v != 0xffffffffu) continue;   // OBNSL_PROBE_NOSTORE: nothing is written
         uint32_t* dst = counts + base + (uint64_t)c * M;
         if (atomics) {
           if (v) atomicAdd(dst, v);
@@ -686,6 +708,7 @@ __device__ __forceinline__ void mfma_tile_body(
 struct MfmaUnit {
   uint32_t row_tile, col_tile, step_lo, step_hi;
   uint32_t blocks;   // 32-column blocks of the tile that hold a valid column (>= 1)
+  uint32_t tile;     // index of the tile in the launch's tile list (its image, see below)
 };
 
 // TB = 128: 4 waves, two workgroups per CU.  TB = 256: 8 waves, one workgroup per CU --
@@ -704,10 +727,12 @@ __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void b
   constexpr uint32_t JFULL = TB / 32;
   const uint32_t jm = (use_atomics & 2) ? JFULL : u.blocks;
   const bool atomics = (use_atomics & 1) != 0 && !(use_atomics & 8);
+  // image mode: `counts` is the launch's array of tile images
+  uint32_t* image = (use_atomics & 1024) ? counts + (size_t)u.tile * (TB * TB) : nullptr;
 #define OBNSL_MFMA_BODY(NA, NB)                                                                          \
   mfma_tile_body<KR, KC, NA, NB, TB>(smem, planes, wp, rows, nrows, cols, ncols_total, row0, col0, counts, \
-                                     u.step_lo, u.step_hi, atomics, (use_atomics & 4) != 0,              \
-                                     (use_atomics & 32) != 0, (use_atomics >> 6) & 3)
+                                     u.step_lo, u.step_hi, atomics, image, (use_atomics & 4) != 0,       \
+                                     (use_atomics & 32) != 0, (use_atomics >> 6) & 7)
   switch (jm) {  // uniform over the workgroup
     case 1: OBNSL_MFMA_BODY(1, 1); break;
     case 2: OBNSL_MFMA_BODY(1, 2); break;
@@ -723,6 +748,27 @@ __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void b
       break;
   }
 #undef OBNSL_MFMA_BODY
+}
+
+// Moves the finished tile images of a split-contraction launch into the count table:
+// one workgroup per (tile, 8 rows), a half-wave per row, every valid (row, column) cell
+// exactly once (plain stores: the table needs no clearing).
+template <int TB>
+__global__ __launch_bounds__(256) void image_scatter_kernel(
+    const uint32_t* __restrict__ images, const uint2* __restrict__ items,
+    const RowDesc* __restrict__ rows, uint32_t nrows, uint32_t* __restrict__ counts) {
+  const uint32_t tile = blockIdx.x / (TB / 8), r8 = blockIdx.x % (TB / 8);
+  const uint2 it = items[tile];
+  const uint32_t rin = r8 * 8 + (threadIdx.x >> 5), lane = threadIdx.x & 31;
+  const uint32_t r = it.x * TB + rin;
+  if (r >= nrows) return;
+  const RowDesc rd = rows[r];
+  const uint32_t* src = images + (size_t)tile * (TB * TB) + rin * TB;
+#pragma unroll
+  for (int cb = 0; cb < TB / 32; ++cb) {
+    const uint32_t c = it.y * TB + cb * 32 + lane;
+    if (c < rd.ncols) counts[rd.out_base + (uint64_t)c * rd.M] = src[cb * 32 + lane];
+  }
 }
 
 // ------------------------------------------------------------------ single table
@@ -1534,6 +1580,9 @@ struct Batch {
   DevBuf<MfmaUnit> units;              // matrix-core launch: work units for `units_steps` steps
   uint32_t nunits = 0, units_steps = 0, units_target = 0;
   bool units_split = false;            // some tile is cut into several units (atomics needed)
+  DevBuf<uint32_t> img;                // split launches: one row-major tile x tile image per item
+  uint64_t img_zeroed_epoch = 0;       // data epoch at whose pack `img` was cleared
+  bool img_wants_zero = false;         // the last launch added into `img`
   DevBuf<RowGroupDesc> rgs;
   uint32_t nrows = 0, nitems = 0, nrgs = 0;
   uint64_t ntables = 0, ncells = 0;
@@ -1565,6 +1614,7 @@ struct Plan {
   uint64_t zeroed_epoch = 0;    // data epoch at whose pack `red` was cleared
   bool wants_zero = false;      // the last count into `red` added with atomics (or filled a slice of it)
   uint64_t slice_off = 0;       // sharded plan: where its counters sit inside the whole plan's `red`
+  uint64_t size_cells = 0;      // counters of ALL tables of this subset size (the same for every shard)
   bool awaits_sum = false;      // whole plan: `red` holds one rank's slice, the sum over ranks is pending
   uint64_t total_items = 0;
   // per-table functional G[colex rank] of this plan's tables (see score_reduced_kernel)
@@ -1820,6 +1870,7 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
   }
 
   plan->slice_off = rsub.empty() ? 0 : cum[std::min(g_lo, rsub.size())];
+  plan->size_cells = total_cost;
   std::vector<uint64_t> rowoff;
   if (reduced) rowoff.assign(binom_host(n, kr), 0);
   const uint64_t cell_cap = reduced ? (1ull << 33) : BATCH_CELL_CAP;
@@ -2010,6 +2061,7 @@ obnsl_status build_units(Batch* b, uint32_t steps_total, uint32_t target) {
       u.step_lo = (uint32_t)((uint64_t)steps_total * sidx / ns);
       u.step_hi = (uint32_t)((uint64_t)steps_total * (sidx + 1) / ns);
       u.blocks = blk;
+      u.tile = (uint32_t)i;
       tmp.push_back({weight(blk) * (u.step_hi - u.step_lo), u});
     }
   }
@@ -2019,6 +2071,15 @@ obnsl_status build_units(Batch* b, uint32_t steps_total, uint32_t target) {
                    });
   units.reserve(tmp.size());
   for (auto& t : tmp) units.push_back(t.second);
+  static const bool dump = std::getenv("OBNSL_DUMP_UNITS") != nullptr;   // tools/mfma_rate.py
+  if (dump) {
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> hist;
+    for (auto& t : tmp) hist[{t.second.blocks, t.second.step_hi - t.second.step_lo}]++;
+    std::fprintf(stderr, "units: %zu tiles, %zu units, steps %u, target %u\n", b->h_items.size(),
+                 tmp.size(), steps_total, target);
+    for (auto& h : hist)
+      std::fprintf(stderr, "  blocks %u steps %u: %u units\n", h.first.first, h.first.second, h.second);
+  }
   HIP_TRY(b->units.upload(units));
   b->nunits = (uint32_t)units.size();
   b->units_steps = steps_total;
@@ -2031,13 +2092,15 @@ obnsl_status build_units(Batch* b, uint32_t steps_total, uint32_t target) {
 // than in shards (one 128 x 128 matrix-core tile is sixteen 64 x 64 ones).
 uint64_t whole_below(const Plan* p) { return p->mfma ? 4 : 64; }
 
-// Units per matrix-core launch by number of tiles (OBNSL_WANT="a,b,c" overrides: tuning runs).
+// Units per matrix-core launch by number of tiles: one or two tiles, up to 32, more
+// without and with tile images (OBNSL_WANT="a,b,c[,d]" overrides: tuning runs).
 uint32_t want_tier(int tier) {
   static const std::vector<uint32_t> t = [] {
-    std::vector<uint32_t> v = {64u, 384u, 896u};
+    std::vector<uint32_t> v = {64u, 384u, 896u, 4096u};
     if (const char* e = std::getenv("OBNSL_WANT")) {
-      unsigned a = 0, b = 0, c = 0;
-      if (std::sscanf(e, "%u,%u,%u", &a, &b, &c) == 3 && a && b && c) v = {a, b, c};
+      unsigned a = 0, b = 0, c = 0, f = 0;
+      const int got = std::sscanf(e, "%u,%u,%u,%u", &a, &b, &c, &f);
+      if (got >= 3 && a && b && c) v = {a, b, c, got == 4 && f ? f : c};
     }
     return v;
   }();
@@ -2061,13 +2124,21 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   // 512 are enough, and every extra split adds the whole table in atomics
   // (measured on the 37-variable workload, whole pass: one tile cut into ~64 units -- 16
   // units of ~64 steps when it runs beside a launch of many tiles, whose workgroup slots
-  // it would take --, 17 tiles into ~384, 64 tiles into ~896: short units pay their
-  // prologue and epilogue, long ones leave CUs idle at the end of the launch)
+  // it would take --, 17 tiles into ~384, 63 tiles into ~4096 when the units add into
+  // tile images, ~896 when they add into the table with scattered atomics: short units
+  // pay their prologue and epilogue, long ones leave CUs idle at the end of the launch)
+  // split launches of 128 x 128 tiles add into tile images (up to IMAGE_MAX_BYTES of
+  // them) instead of the count table itself; OBNSL_NO_IMAGE: comparison runs
+  static const bool no_image = std::getenv("OBNSL_NO_IMAGE") != nullptr;
+  const uint64_t img_cells = (uint64_t)b->nitems * plan->tile * plan->tile;
+  const bool image_ok = plan->mfma && plan->tile == 128 && !no_image &&
+                        img_cells * sizeof(uint32_t) <= IMAGE_MAX_BYTES;
   const uint32_t want = want_env ? want_env
                         : !plan->mfma ? 8192u
                         : b->nitems <= 2 ? (d->beside_large ? std::min(want_tier(0), std::max(16u, steps_total / 64))
                                                             : want_tier(0))
-                        : b->nitems <= 32 ? want_tier(1) : want_tier(2);
+                        : b->nitems <= 32 ? want_tier(1)
+                        : image_ok ? want_tier(3) : want_tier(2);
   static const uint32_t min_sps = [] {
     const char* e = std::getenv("OBNSL_MIN_SPS");
     return e ? std::max(1u, (uint32_t)std::atoi(e)) : 8u;
@@ -2081,15 +2152,29 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
                              (std::getenv("OBNSL_PROBE_NOATOMIC") ? 8 : 0) |
                              (std::getenv("OBNSL_NO_2X2") ? 16 : 0) |
                              (std::getenv("OBNSL_PROBE_SAMELOAD") ? 32 : 0) |
-                             (std::getenv("OBNSL_PROBE_NOWRITE") ? 64 : 0) | (std::getenv("OBNSL_PROBE_NOISSUE") ? 128 : 0);
+                             (std::getenv("OBNSL_PROBE_NOWRITE") ? 64 : 0) | (std::getenv("OBNSL_PROBE_NOISSUE") ? 128 : 0) |
+                             (std::getenv("OBNSL_PROBE_NOSTORE") ? 256 : 0);
   if (plan->mfma) {
     obnsl_status st = build_units(b, steps_total, std::max(want, b->nitems));
     if (st != OBNSL_OK) return st;
   }
-  const int atomics = ((plan->mfma ? b->units_split : ksplit > 1) ? 1 : 0) | nojskip;
-  if ((atomics & 1) && !prezeroed)
-    HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
-  if (counts == plan->red.p) plan->wants_zero = (atomics & 1) != 0;
+  int atomics = ((plan->mfma ? b->units_split : ksplit > 1) ? 1 : 0) | nojskip;
+  const bool image = image_ok && (atomics & 1);
+  uint32_t* table = counts;
+  if (image) {
+    HIP_TRY(b->img.ensure(img_cells));
+    if (b->img_zeroed_epoch != d->epoch)
+      HIP_TRY(hipMemsetAsync(b->img.p, 0, img_cells * sizeof(uint32_t), d->count_stream()));
+    b->img_zeroed_epoch = 0;   // about to be added into
+    b->img_wants_zero = true;
+    atomics |= 1024;
+    counts = b->img.p;
+    if (table == plan->red.p) plan->wants_zero = false;  // every cell is stored, none added into
+  } else {
+    if ((atomics & 1) && !prezeroed)
+      HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
+    if (counts == plan->red.p) plan->wants_zero = (atomics & 1) != 0;
+  }
   if (d->ev_used >= 4096) {  // bound the pool: fold what has been recorded so far
     obnsl_status st = resolve_events(d);
     if (st != OBNSL_OK) return st;
@@ -2117,6 +2202,11 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
     default: return fail(OBNSL_ERR_RUNTIME, "internal: no bit-GEMM instance");
   }
   HIP_TRY(hipGetLastError());
+  if (image) {
+    hipLaunchKernelGGL(image_scatter_kernel<128>, dim3(b->nitems * (128 / 8)), dim3(256), 0, d->count_stream(),
+                       b->img.p, b->items.p, b->rows.p, b->nrows, table);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipEventRecord(ev.second, d->count_stream()));
   return OBNSL_OK;
 }
@@ -2187,8 +2277,15 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
     uint32_t tpw = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(2, b->ntables / 2048));
     if (tpw_env) tpw = tpw_env;
     // four tables per wavefront when the tables are small (full tables of at most 256
-    // cells, 32 counted cells per table on average), else two
-    const uint32_t parts = (max_cells <= 256 && b->ncells <= 32 * b->ntables) ? 4 : 2;
+    // cells, 32 counted cells per table on average over the whole size), else two.  A
+    // property of the subset size alone: G of a size must come out bit for bit the same
+    // whether it is computed for its own scores, for the next size's, whole or in shards
+    // (the two forms sum a table's cells in different orders).
+    std::vector<uint32_t> sorted_card(d->card);
+    std::sort(sorted_card.rbegin(), sorted_card.rend());
+    uint64_t own_max_cells = 1, all_tables = binom_host(d->n, k);
+    for (uint32_t i = 0; i < k; ++i) own_max_cells *= sorted_card[i];
+    const uint32_t parts = (own_max_cells <= 256 && plan->size_cells <= 32 * all_tables) ? 4 : 2;
     tpw = (tpw + parts - 1) / parts * parts;  // a wavefront takes its tables `parts` at a time
     const uint32_t grid = (uint32_t)((b->ntables + tpw - 1) / tpw);
     const uint32_t e_stride = (uint32_t)((max_cells + 3) & ~3ull);
@@ -2361,12 +2458,24 @@ obnsl_status run_pack(obnsl_data* d, uint32_t* bad_code = nullptr) {
   ZeroList zl;
   std::memset(&zl, 0, sizeof(zl));
   Plan* cleared[ZERO_MAX];
+  int ncleared = 0;
+  Batch* cleared_img[ZERO_MAX];
+  int nimg = 0;
   for (auto& kv : d->plans) {
     Plan* p = kv.second.get();
     if (zl.count == ZERO_MAX) break;
-    if (!p->reduced || !p->wants_zero || p->counted_epoch != d->epoch || !p->red.p) continue;
+    if (!p->reduced || p->counted_epoch != d->epoch) continue;
+    Batch* b0 = p->batches.empty() ? nullptr : p->batches[0].get();
+    if (b0 && b0->img_wants_zero && b0->img.p) {   // the tile images of its split launch
+      cleared_img[nimg++] = b0;
+      zl.p[zl.count] = b0->img.p;
+      zl.n[zl.count] = (uint64_t)b0->nitems * p->tile * p->tile;
+      ++zl.count;
+      if (zl.count == ZERO_MAX) break;
+    }
+    if (!p->wants_zero || !p->red.p) continue;
     if (p->batches[0]->ncells > (1ull << 26)) continue;  // large tables keep their own fill
-    cleared[zl.count] = p;
+    cleared[ncleared++] = p;
     zl.p[zl.count] = p->red.p;
     zl.n[zl.count] = p->batches[0]->ncells;
     ++zl.count;
@@ -2377,7 +2486,11 @@ obnsl_status run_pack(obnsl_data* d, uint32_t* bad_code = nullptr) {
                      d->ones_plane, bad_code, zl);
   HIP_TRY(hipGetLastError());
   d->epoch++;  // every cached count table is stale now
-  for (int i = 0; i < zl.count; ++i) cleared[i]->zeroed_epoch = d->epoch;
+  for (int i = 0; i < ncleared; ++i) cleared[i]->zeroed_epoch = d->epoch;
+  for (int i = 0; i < nimg; ++i) {
+    cleared_img[i]->img_zeroed_epoch = d->epoch;
+    cleared_img[i]->img_wants_zero = false;
+  }
   return OBNSL_OK;
 }
 

@@ -17,6 +17,6 @@ end = 0
 for r in rows[lo:]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     end = max(end, e)
-    name = r["Kernel_Name"].split("(")[0][-60:]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:48]
     print(f"{s/1000:9.1f} us  +{(e-s)/1000:8.1f} us  q{r.get('Queue_Id','?'):>3}  {name}")
 print(f"pass: {end/1000:.1f} us")
