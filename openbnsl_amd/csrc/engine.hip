@@ -484,7 +484,7 @@ __device__ __forceinline__ void tile_mfma(const uint32_t* __restrict__ sA,
 }
 
 constexpr int MFMA_TILE = 128;        // tile edge of the matrix-core kernel (256 for launches of many tiles)
-constexpr uint64_t IMAGE_MAX_BYTES = 64ull << 20;  // tile images of one split launch (1024 tiles)
+constexpr uint64_t IMAGE_MAX_BYTES = 256ull << 20;  // tile images of one split launch (4096 tiles)
 constexpr size_t BIG_TILE_FROM = 16384;  // 128 x 128 tiles from which a launch takes 256 x 256 tiles
 constexpr uint32_t MFMA_MAX_STEPS = (1u << 24) / (KCW * 32);  // samples per workgroup < 2^24
 
@@ -2124,21 +2124,29 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   // 512 are enough, and every extra split adds the whole table in atomics
   // (measured on the 37-variable workload, whole pass: one tile cut into ~64 units -- 16
   // units of ~64 steps when it runs beside a launch of many tiles, whose workgroup slots
-  // it would take --, 17 tiles into ~384, 63 tiles into ~4096 when the units add into
-  // tile images, ~896 when they add into the table with scattered atomics: short units
-  // pay their prologue and epilogue, long ones leave CUs idle at the end of the launch)
+  // it would take --, 17 tiles into ~384, more tiles into ~4096 units, at least two per
+  // tile and up to 16384 of ~256 steps (70 variables, 10^7 rows: 306 tiles, +5 % from 4096
+  // to 8192..16384 units) when the units add into tile images, ~896 when they add into the
+  // table with scattered atomics: short units pay their prologue and epilogue, long ones
+  // leave CUs idle at the end of the launch)
   // split launches of 128 x 128 tiles add into tile images (up to IMAGE_MAX_BYTES of
   // them) instead of the count table itself; OBNSL_NO_IMAGE: comparison runs
   static const bool no_image = std::getenv("OBNSL_NO_IMAGE") != nullptr;
+  static const uint64_t image_max = [] {
+    const char* e = std::getenv("OBNSL_IMAGE_MB");
+    return e ? (uint64_t)std::atoi(e) << 20 : IMAGE_MAX_BYTES;
+  }();
   const uint64_t img_cells = (uint64_t)b->nitems * plan->tile * plan->tile;
   const bool image_ok = plan->mfma && plan->tile == 128 && !no_image &&
-                        img_cells * sizeof(uint32_t) <= IMAGE_MAX_BYTES;
+                        img_cells * sizeof(uint32_t) <= image_max;
   const uint32_t want = want_env ? want_env
                         : !plan->mfma ? 8192u
                         : b->nitems <= 2 ? (d->beside_large ? std::min(want_tier(0), std::max(16u, steps_total / 64))
                                                             : want_tier(0))
                         : b->nitems <= 32 ? want_tier(1)
-                        : image_ok ? want_tier(3) : want_tier(2);
+                        : image_ok ? std::max({want_tier(3), 2 * b->nitems,
+                                               (uint32_t)std::min<uint64_t>((uint64_t)b->nitems * steps_total / 256, 16384)})
+                                   : want_tier(2);
   static const uint32_t min_sps = [] {
     const char* e = std::getenv("OBNSL_MIN_SPS");
     return e ? std::max(1u, (uint32_t)std::atoi(e)) : 8u;
