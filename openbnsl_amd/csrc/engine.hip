@@ -1039,7 +1039,8 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
     uint64_t ntables, uint32_t tables_per_wg, const uint32_t* __restrict__ card,
     const uint64_t* __restrict__ binom, uint32_t num_rows, int kind, double ess,
     double* __restrict__ G, const double* __restrict__ Gprev, double g0,
-    double* __restrict__ scores, const double* __restrict__ lg_alpha, uint32_t e_stride) {
+    double* __restrict__ scores, const double* __restrict__ lg_alpha, uint32_t e_stride,
+    const uint32_t* __restrict__ wg_rg) {
   // The wavefront works on PARTS tables at a time (2 or 4: 32 or 16 lanes each):
   // a table is a chain of dependent loads (descriptors -> table bases -> counts
   // -> G of the subsets below), and several chains in flight per wave hide more
@@ -1060,14 +1061,9 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
     if (threadIdx.x == (uint32_t)j) sv[j] = views.v[j];
   const uint64_t t0 = (uint64_t)blockIdx.x * tables_per_wg;
   const uint64_t t1 = min(t0 + (uint64_t)tables_per_wg, ntables);
-  // row group of this half's first table; its later tables advance through the groups
-  const uint64_t first = min(t0 + half, ntables - 1);
-  uint32_t g = 0, hi = nrgs - 1;
-  while (g < hi) {
-    const uint32_t mid = (g + hi + 1) >> 1;
-    if (rgs[mid].tbl_start <= first) g = mid;
-    else hi = mid - 1;
-  }
+  // row group of the workgroup's first table (from the host: one load instead of a
+  // binary search of dependent loads); every part advances from there through the groups
+  uint32_t g = wg_rg[blockIdx.x];
   RowGroupDesc rg = rgs[g];
   const uint32_t kc = k / 2, kr = k - kc;
   __syncthreads();
@@ -1580,6 +1576,9 @@ struct Batch {
   DevBuf<MfmaUnit> units;              // matrix-core launch: work units for `units_steps` steps
   uint32_t nunits = 0, units_steps = 0, units_target = 0;
   bool units_split = false;            // some tile is cut into several units (atomics needed)
+  std::vector<uint64_t> h_tbl_start;   // first table of every row group (host copy)
+  DevBuf<uint32_t> wg_rg;              // scorer: row group of each workgroup's first table ...
+  uint32_t wg_rg_tpw = 0;              // ... for this many tables per workgroup
   DevBuf<uint32_t> img;                // split launches: one row-major tile x tile image per item
   uint64_t img_zeroed_epoch = 0;       // data epoch at whose pack `img` was cleared
   bool img_wants_zero = false;         // the last launch added into `img`
@@ -1976,6 +1975,8 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     HIP_TRY(b->rows.upload(rows));
     HIP_TRY(b->items.upload(items));
     HIP_TRY(b->rgs.upload(rgs));
+    b->h_tbl_start.resize(rgs.size());
+    for (size_t i = 0; i < rgs.size(); ++i) b->h_tbl_start[i] = rgs[i].tbl_start;
     plan->total_items += b->nitems;
     plan->batches.push_back(std::move(b));
   }
@@ -2130,14 +2131,16 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   // table with scattered atomics: short units pay their prologue and epilogue, long ones
   // leave CUs idle at the end of the launch)
   // split launches of 128 x 128 tiles add into tile images (up to IMAGE_MAX_BYTES of
-  // them) instead of the count table itself; OBNSL_NO_IMAGE: comparison runs
+  // them) instead of the count table itself -- not the launches of one or two tiles:
+  // their few units' atomics cost less than the scatter launch; OBNSL_NO_IMAGE:
+  // comparison runs
   static const bool no_image = std::getenv("OBNSL_NO_IMAGE") != nullptr;
   static const uint64_t image_max = [] {
     const char* e = std::getenv("OBNSL_IMAGE_MB");
     return e ? (uint64_t)std::atoi(e) << 20 : IMAGE_MAX_BYTES;
   }();
   const uint64_t img_cells = (uint64_t)b->nitems * plan->tile * plan->tile;
-  const bool image_ok = plan->mfma && plan->tile == 128 && !no_image &&
+  const bool image_ok = plan->mfma && plan->tile == 128 && !no_image && b->nitems > 2 &&
                         img_cells * sizeof(uint32_t) <= image_max;
   const uint32_t want = want_env ? want_env
                         : !plan->mfma ? 8192u
@@ -2274,9 +2277,9 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
     }
     lg_alpha = slot->p;
   }
-  const Batch* b = plan->batches[0].get();
+  Batch* b = plan->batches[0].get();
   if (b->ntables) {
-    // a few consecutive tables per wavefront amortise the row-group search and
+    // a few consecutive tables per wavefront amortise the descriptor loads and
     // the dispatch; keep at least ~16 workgroups per CU for latency hiding
     static const uint32_t tpw_env = [] {
       const char* e = std::getenv("OBNSL_TABLES_PER_WG");
@@ -2297,11 +2300,22 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
     tpw = (tpw + parts - 1) / parts * parts;  // a wavefront takes its tables `parts` at a time
     const uint32_t grid = (uint32_t)((b->ntables + tpw - 1) / tpw);
     const uint32_t e_stride = (uint32_t)((max_cells + 3) & ~3ull);
+    if (b->wg_rg_tpw != tpw) {   // row group of every workgroup's first table (once per plan)
+      std::vector<uint32_t> h(grid);
+      size_t g = 0;
+      for (uint32_t w = 0; w < grid; ++w) {
+        const uint64_t t0 = (uint64_t)w * tpw;
+        while (g + 1 < b->h_tbl_start.size() && b->h_tbl_start[g + 1] <= t0) ++g;
+        h[w] = (uint32_t)g;
+      }
+      HIP_TRY(b->wg_rg.upload(h));
+      b->wg_rg_tpw = tpw;
+    }
 #define OBNSL_LAUNCH_SCORER_P(KT, P)                                                             \
   hipLaunchKernelGGL((score_reduced_kernel<KT, P>), dim3(grid), dim3(64),                        \
                      (size_t)P * e_stride * sizeof(uint32_t), d->stream, views, b->rgs.p,        \
                      b->nrgs, b->ntables, tpw, d->d_card.p, d->d_binom.p, (uint32_t)d->N,        \
-                     (int)kind, ess, plan->G.p, gprev, g0, scores, lg_alpha, e_stride)
+                     (int)kind, ess, plan->G.p, gprev, g0, scores, lg_alpha, e_stride, b->wg_rg.p)
 #define OBNSL_LAUNCH_SCORER(KT)            \
   do {                                     \
     if (parts == 4) OBNSL_LAUNCH_SCORER_P(KT, 4); \
