@@ -21,13 +21,17 @@
 // The contraction runs on the matrix cores (bitgemm_mfma_kernel): a sample bit
 // becomes an FP4 nibble by masking, v_mfma_scale_f32_32x32x64_f8f6f4 multiplies
 // and adds 32 x 32 x 64 of them per instruction, and the f32 accumulators hold
-// exact integer counts.  A workgroup owns a 128 x 128 tile of C and stages
-// 32-word slabs of A and B through LDS (rows formed on the fly by ANDing the
-// subset's planes).  bitgemm_kernel is the same contraction as AND + popcount on
-// the vector ALU (OBNSL_GEMM=valu; 64 x 64 tiles).  Tables with many cells, and
-// subsets of more than 8 variables, are counted per row instead
-// (count_hist_kernel).  Scores come from one functional per table, G(S) - G(P),
-// evaluated in fp64 by score_reduced_kernel, two tables per wavefront.
+// exact integer counts.  A workgroup owns a 128 x 128 tile of C (256 x 256 in
+// launches of very many tiles) and stages 32-word slabs of A and B through LDS
+// (rows formed on the fly by ANDing the subset's planes).  A launch of few tiles
+// is cut along the contraction into thousands of work units; their partial
+// counts meet in row-major images of the tiles (coalesced atomics) that
+// image_scatter_kernel moves into the count table.  bitgemm_kernel is the same
+// contraction as AND + popcount on the vector ALU (OBNSL_GEMM=valu; 64 x 64
+// tiles).  Tables with many cells, and subsets of more than 8 variables, are
+// counted per row instead (count_hist_kernel).  Scores come from one functional
+// per table, G(S) - G(P), evaluated in fp64 by score_reduced_kernel, two or four
+// tables per wavefront.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
