@@ -487,6 +487,72 @@ __device__ __forceinline__ void tile_mfma(const uint32_t* __restrict__ sA,
   }
 }
 
+// 2 x 2 blocks, software pipelined: the operands of block J + 1 are built between
+// the instructions of block J (scheduling groups: one MFMA, then up to 8 vector
+// instructions), so a wave's matrix instructions are not held up by its own builds.
+template <int J>
+__device__ __forceinline__ void build_2x2(const uint4 (&wa)[2], const uint4 (&wb)[2], obnsl_v8i (&a)[2],
+                                          obnsl_v8i (&b)[2]) {
+  a[0] = fp4_operand<J>(wa[0]);
+  a[1] = fp4_operand<J>(wa[1]);
+  b[0] = fp4_operand<J>(wb[0]);
+  b[1] = fp4_operand<J>(wb[1]);
+}
+template <int J>
+__device__ __forceinline__ void mfma_2x2(const obnsl_v8i (&a)[2], const obnsl_v8i (&b)[2],
+                                         obnsl_v16f (&acc)[2][2]) {
+  acc[0][0] = fp4_mfma<J>(a[0], b[0], acc[0][0]);
+  acc[1][0] = fp4_mfma<J>(a[1], b[0], acc[1][0]);
+  acc[0][1] = fp4_mfma<J>(a[0], b[1], acc[0][1]);
+  acc[1][1] = fp4_mfma<J>(a[1], b[1], acc[1][1]);
+}
+template <class AfterRound>
+__device__ __forceinline__ void tile_mfma_pipelined(const uint32_t* __restrict__ sA,
+                                                    const uint32_t* __restrict__ sB, uint32_t arow,
+                                                    uint32_t brow, uint32_t hoff, obnsl_v16f (&acc)[2][2],
+                                                    AfterRound after_round) {
+  const uint32_t* pa = &sA[arow * LDS_STRIDE + hoff];
+  const uint32_t* pb = &sB[brow * LDS_STRIDE + hoff];
+  uint4 wa[2], wb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE);
+    wb[i] = *reinterpret_cast<const uint4*>(pb + 32 * i * LDS_STRIDE);
+  }
+  obnsl_v8i oa[2], ob[2];
+  build_2x2<0>(wa, wb, oa, ob);
+#pragma unroll 1
+  for (int rd = 0; rd < KCW / 8; ++rd) {
+    const int nx = min(rd + 1, KCW / 8 - 1) * 8;
+    uint4 na[2], nb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      na[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
+      nb[i] = *reinterpret_cast<const uint4*>(pb + 32 * i * LDS_STRIDE + nx);
+    }
+    obnsl_v8i qa[2], qb[2];
+#define OBNSL_PIPE(J, JN, SRCA, SRCB)                                  \
+    mfma_2x2<J>(oa, ob, acc);                                          \
+    build_2x2<JN>(SRCA, SRCB, qa, qb);                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                    \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               \
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);               \
+    }                                                                  \
+    oa[0] = qa[0]; oa[1] = qa[1]; ob[0] = qb[0]; ob[1] = qb[1];
+    OBNSL_PIPE(0, 1, wa, wb)
+    OBNSL_PIPE(1, 2, wa, wb)
+    OBNSL_PIPE(2, 3, wa, wb)
+    OBNSL_PIPE(3, 0, na, nb)
+#undef OBNSL_PIPE
+    after_round(rd);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      wa[i] = na[i];
+      wb[i] = nb[i];
+    }
+  }
+}
+
 constexpr int MFMA_TILE = 128;        // tile edge of the matrix-core kernel (256 for launches of many tiles)
 constexpr uint64_t IMAGE_MAX_BYTES = 256ull << 20;  // tile images of one split launch (4096 tiles)
 constexpr size_t BIG_TILE_FROM = 16384;  // 128 x 128 tiles from which a launch takes 256 x 256 tiles
@@ -598,7 +664,8 @@ __device__ __forceinline__ void mfma_tile_body(
       if (more && !(probe_x & 2)) issue_loads(step + 1);
       const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
       const uint32_t* sB = sA + TB * LDS_STRIDE;
-      tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
+      if constexpr (NA == 2 && NB == 2) tile_mfma_pipelined(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
+      else tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
       if (more && !(probe_x & 1)) write_slab(buf ^ 1);
       __syncthreads();
     }
