@@ -521,16 +521,13 @@ __device__ __forceinline__ void tile_mfma_pipelined(const uint32_t* __restrict__
   }
   obnsl_v8i oa[2], ob[2];
   build_2x2<0>(wa, wb, oa, ob);
+  static_assert(KCW / 8 == 4, "two iterations of two rounds");
+  // two rounds per iteration: the words of a round live in (wa, wb) and (na, nb) in
+  // turn, so no round ends with copying one set into the other
 #pragma unroll 1
-  for (int rd = 0; rd < KCW / 8; ++rd) {
-    const int nx = min(rd + 1, KCW / 8 - 1) * 8;
-    uint4 na[2], nb[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      na[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
-      nb[i] = *reinterpret_cast<const uint4*>(pb + 32 * i * LDS_STRIDE + nx);
-    }
+  for (int rp = 0; rp < 2; ++rp) {
     obnsl_v8i qa[2], qb[2];
+    uint4 na[2], nb[2];
 #define OBNSL_PIPE(J, JN, SRCA, SRCB)                                  \
     mfma_2x2<J>(oa, ob, acc);                                          \
     build_2x2<JN>(SRCA, SRCB, qa, qb);                                 \
@@ -539,17 +536,34 @@ __device__ __forceinline__ void tile_mfma_pipelined(const uint32_t* __restrict__
       __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);               \
     }                                                                  \
     oa[0] = qa[0]; oa[1] = qa[1]; ob[0] = qb[0]; ob[1] = qb[1];
-    OBNSL_PIPE(0, 1, wa, wb)
-    OBNSL_PIPE(1, 2, wa, wb)
-    OBNSL_PIPE(2, 3, wa, wb)
-    OBNSL_PIPE(3, 0, na, nb)
-#undef OBNSL_PIPE
-    after_round(rd);
+    {  // round 2 rp: its words are in (wa, wb); the next round's go to (na, nb)
+      const int nx = (2 * rp + 1) * 8;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      wa[i] = na[i];
-      wb[i] = nb[i];
+      for (int i = 0; i < 2; ++i) {
+        na[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
+        nb[i] = *reinterpret_cast<const uint4*>(pb + 32 * i * LDS_STRIDE + nx);
+      }
+      OBNSL_PIPE(0, 1, wa, wb)
+      OBNSL_PIPE(1, 2, wa, wb)
+      OBNSL_PIPE(2, 3, wa, wb)
+      OBNSL_PIPE(3, 0, na, nb)
+      after_round(2 * rp);
     }
+    {  // round 2 rp + 1: its words are in (na, nb); the next round's go to (wa, wb)
+      // (the last round reads its own words again: one address computation for every round)
+      const int nx = min(2 * rp + 2, KCW / 8 - 1) * 8;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
+        wb[i] = *reinterpret_cast<const uint4*>(pb + 32 * i * LDS_STRIDE + nx);
+      }
+      OBNSL_PIPE(0, 1, na, nb)
+      OBNSL_PIPE(1, 2, na, nb)
+      OBNSL_PIPE(2, 3, na, nb)
+      OBNSL_PIPE(3, 0, wa, wb)
+      after_round(2 * rp + 1);
+    }
+#undef OBNSL_PIPE
   }
 }
 
