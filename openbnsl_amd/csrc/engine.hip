@@ -464,26 +464,40 @@ __device__ __forceinline__ void tile_mfma(const uint32_t* __restrict__ sA,
   for (int i = 0; i < NA; ++i) wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE);
 #pragma unroll
   for (int j = 0; j < NB; ++j) wb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE);
+  static_assert(KCW / 8 == 4, "two iterations of two rounds");
+  // two rounds per iteration: the words of a round live in (wa, wb) and (na, nb) in turn
 #pragma unroll 1
-  for (int rd = 0; rd < KCW / 8; ++rd) {
-    // (the last round reads its own words again: one address computation for every round)
-    const int nx = min(rd + 1, KCW / 8 - 1) * 8;
+  for (int rp = 0; rp < 2; ++rp) {
     uint4 na[NA], nb[NB];
+    {
+      const int nx = (2 * rp + 1) * 8;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) na[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
+      for (int i = 0; i < NA; ++i) na[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) nb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE + nx);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block<NA, NB, 0>(wa, wb, acc);
-    mfma_block<NA, NB, 1>(wa, wb, acc);
-    mfma_block<NA, NB, 2>(wa, wb, acc);
-    mfma_block<NA, NB, 3>(wa, wb, acc);
-    after_round(rd);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < NB; ++j) nb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE + nx);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block<NA, NB, 0>(wa, wb, acc);
+      mfma_block<NA, NB, 1>(wa, wb, acc);
+      mfma_block<NA, NB, 2>(wa, wb, acc);
+      mfma_block<NA, NB, 3>(wa, wb, acc);
+      after_round(2 * rp);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      // (the last round reads its own words again: one address computation for every round)
+      const int nx = min(2 * rp + 2, KCW / 8 - 1) * 8;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) wa[i] = na[i];
+      for (int i = 0; i < NA; ++i) wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) wb[j] = nb[j];
+      for (int j = 0; j < NB; ++j) wb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE + nx);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block<NA, NB, 0>(na, nb, acc);
+      mfma_block<NA, NB, 1>(na, nb, acc);
+      mfma_block<NA, NB, 2>(na, nb, acc);
+      mfma_block<NA, NB, 3>(na, nb, acc);
+      after_round(2 * rp + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
