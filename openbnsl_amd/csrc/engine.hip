@@ -501,62 +501,62 @@ __device__ __forceinline__ void tile_mfma(const uint32_t* __restrict__ sA,
   }
 }
 
-// 2 x 2 blocks, software pipelined: the operands of block J + 1 are built between
-// the instructions of block J (scheduling groups: one MFMA, then up to 8 vector
-// instructions), so a wave's matrix instructions are not held up by its own builds.
-template <int J>
-__device__ __forceinline__ void build_2x2(const uint4 (&wa)[2], const uint4 (&wb)[2], obnsl_v8i (&a)[2],
-                                          obnsl_v8i (&b)[2]) {
-  a[0] = fp4_operand<J>(wa[0]);
-  a[1] = fp4_operand<J>(wa[1]);
-  b[0] = fp4_operand<J>(wb[0]);
-  b[1] = fp4_operand<J>(wb[1]);
+// Software pipelined form for NA = 2 (full tiles): the operands of block J + 1 are built
+// between the instructions of block J (scheduling groups: one MFMA, then a share of the
+// vector instructions), so a wave's matrix instructions are not held up by its own builds.
+template <int J, int NA, int NB>
+__device__ __forceinline__ void build_blocks(const uint4 (&wa)[NA], const uint4 (&wb)[NB], obnsl_v8i (&a)[NA],
+                                             obnsl_v8i (&b)[NB]) {
+#pragma unroll
+  for (int i = 0; i < NA; ++i) a[i] = fp4_operand<J>(wa[i]);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) b[j] = fp4_operand<J>(wb[j]);
 }
-template <int J>
-__device__ __forceinline__ void mfma_2x2(const obnsl_v8i (&a)[2], const obnsl_v8i (&b)[2],
-                                         obnsl_v16f (&acc)[2][2]) {
-  acc[0][0] = fp4_mfma<J>(a[0], b[0], acc[0][0]);
-  acc[1][0] = fp4_mfma<J>(a[1], b[0], acc[1][0]);
-  acc[0][1] = fp4_mfma<J>(a[0], b[1], acc[0][1]);
-  acc[1][1] = fp4_mfma<J>(a[1], b[1], acc[1][1]);
+template <int J, int NA, int NB>
+__device__ __forceinline__ void mfma_blocks(const obnsl_v8i (&a)[NA], const obnsl_v8i (&b)[NB],
+                                            obnsl_v16f (&acc)[NA][NB]) {
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i][j] = fp4_mfma<J>(a[i], b[j], acc[i][j]);
 }
-template <class AfterRound>
+template <int NA, int NB, class AfterRound>
 __device__ __forceinline__ void tile_mfma_pipelined(const uint32_t* __restrict__ sA,
                                                     const uint32_t* __restrict__ sB, uint32_t arow,
-                                                    uint32_t brow, uint32_t hoff, obnsl_v16f (&acc)[2][2],
+                                                    uint32_t brow, uint32_t hoff, obnsl_v16f (&acc)[NA][NB],
                                                     AfterRound after_round) {
   const uint32_t* pa = &sA[arow * LDS_STRIDE + hoff];
   const uint32_t* pb = &sB[brow * LDS_STRIDE + hoff];
-  uint4 wa[2], wb[2];
+  uint4 wa[NA], wb[NB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE);
-    wb[i] = *reinterpret_cast<const uint4*>(pb + 32 * i * LDS_STRIDE);
-  }
-  obnsl_v8i oa[2], ob[2];
-  build_2x2<0>(wa, wb, oa, ob);
+  for (int i = 0; i < NA; ++i) wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) wb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE);
+  obnsl_v8i oa[NA], ob[NB];
+  build_blocks<0, NA, NB>(wa, wb, oa, ob);
   static_assert(KCW / 8 == 4, "two iterations of two rounds");
+  constexpr int VPM = (8 * (NA + NB) + NA * NB - 1) / (NA * NB);   // vector instructions per MFMA slot
   // two rounds per iteration: the words of a round live in (wa, wb) and (na, nb) in
   // turn, so no round ends with copying one set into the other
 #pragma unroll 1
   for (int rp = 0; rp < 2; ++rp) {
-    obnsl_v8i qa[2], qb[2];
-    uint4 na[2], nb[2];
+    obnsl_v8i qa[NA], qb[NB];
+    uint4 na[NA], nb[NB];
 #define OBNSL_PIPE(J, JN, SRCA, SRCB)                                  \
-    mfma_2x2<J>(oa, ob, acc);                                          \
-    build_2x2<JN>(SRCA, SRCB, qa, qb);                                 \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                    \
+    mfma_blocks<J, NA, NB>(oa, ob, acc);                               \
+    build_blocks<JN, NA, NB>(SRCA, SRCB, qa, qb);                      \
+    _Pragma("unroll") for (int q = 0; q < NA * NB; ++q) {              \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               \
-      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);               \
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);             \
     }                                                                  \
-    oa[0] = qa[0]; oa[1] = qa[1]; ob[0] = qb[0]; ob[1] = qb[1];
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) oa[i] = qa[i];      \
+    _Pragma("unroll") for (int j = 0; j < NB; ++j) ob[j] = qb[j];
     {  // round 2 rp: its words are in (wa, wb); the next round's go to (na, nb)
       const int nx = (2 * rp + 1) * 8;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        na[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
-        nb[i] = *reinterpret_cast<const uint4*>(pb + 32 * i * LDS_STRIDE + nx);
-      }
+      for (int i = 0; i < NA; ++i) na[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) nb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE + nx);
       OBNSL_PIPE(0, 1, wa, wb)
       OBNSL_PIPE(1, 2, wa, wb)
       OBNSL_PIPE(2, 3, wa, wb)
@@ -567,10 +567,9 @@ __device__ __forceinline__ void tile_mfma_pipelined(const uint32_t* __restrict__
       // (the last round reads its own words again: one address computation for every round)
       const int nx = min(2 * rp + 2, KCW / 8 - 1) * 8;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
-        wb[i] = *reinterpret_cast<const uint4*>(pb + 32 * i * LDS_STRIDE + nx);
-      }
+      for (int i = 0; i < NA; ++i) wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + nx);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) wb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE + nx);
       OBNSL_PIPE(0, 1, na, nb)
       OBNSL_PIPE(1, 2, na, nb)
       OBNSL_PIPE(2, 3, na, nb)
@@ -692,7 +691,7 @@ __device__ __forceinline__ void mfma_tile_body(
       if (more && !(probe_x & 2)) issue_loads(step + 1);
       const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
       const uint32_t* sB = sA + TB * LDS_STRIDE;
-      if constexpr (NA == 2 && NB == 2) tile_mfma_pipelined(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
+      if constexpr (NA == 2 && NB == 2) tile_mfma_pipelined<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
       else tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
       if (more && !(probe_x & 1)) write_slab(buf ^ 1);
       __syncthreads();
@@ -737,12 +736,14 @@ __device__ __forceinline__ void mfma_tile_body(
       if (more && !(probe_x & 2)) issue_pass(step + 1, 0);
       const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
       const uint32_t* sB = sA + TB * LDS_STRIDE;
-      tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [&](int rd) {
+      auto stage_round = [&](int rd) {
         if (more) {
           if (!(probe_x & 1)) write_pass(buf ^ 1, rd);
           if (rd + 1 < NP && !(probe_x & 2)) issue_pass(step + 1, rd + 1);
         }
-      });
+      };
+      if constexpr (NA == 2) tile_mfma_pipelined<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, stage_round);
+      else tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, stage_round);
       __syncthreads();
     }
   }
