@@ -1,4 +1,6 @@
-"""GPU: the 256 x 256 tile form of the matrix-core contraction.
+"""GPU: forms of the matrix-core contraction that the default launches of small data
+sets do not take: 256 x 256 tiles, and split launches that add into the count table
+itself instead of tile images.
 
 Launches of fewer than 16384 tiles take 128 x 128 tiles, so only very wide data
 sets reach the large form by themselves (the 128-variable configuration's
@@ -40,11 +42,14 @@ np.savez(sys.argv[1], **out)
 """
 
 
-def run_child(path, tile):
+def run_child(path, tile, no_image=False):
     env = dict(os.environ)
     env.pop("OBNSL_MFMA_TILE", None)
+    env.pop("OBNSL_NO_IMAGE", None)
     if tile:
         env["OBNSL_MFMA_TILE"] = str(tile)
+    if no_image:
+        env["OBNSL_NO_IMAGE"] = "1"
     out = subprocess.run([sys.executable, "-c", CHILD, path], cwd=ROOT, env=env, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -68,3 +73,14 @@ def test_large_tiles_equal_default_tiles(tmp_path):
             want = oracle.count(codes, card, vs)
             assert int(want.sum()) == 70_001
             assert np.array_equal(big["t%d_%d" % (k, i)], want), (k, vs)
+
+
+def test_split_launches_without_tile_images_equal_default(tmp_path):
+    """Launches whose images would exceed the budget (or that are forced so,
+    OBNSL_NO_IMAGE) add their partial counts into the count table with scattered
+    atomics: same tables, same scores."""
+    direct = run_child(str(tmp_path / "direct.npz"), 0, no_image=True)
+    std = run_child(str(tmp_path / "std.npz"), 0)
+    assert sorted(direct.files) == sorted(std.files)
+    for name in std.files:
+        assert np.array_equal(direct[name], std[name]), name
