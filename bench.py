@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # BASELINE config 2: the configuration the metric is quoted on
+    # 37 variables, 10^6 rows, BDeu, <= 3 parents: the configuration the metric is quoted on
     "alarm37_1e6_bdeu_mp3": dict(gen="alarm", N=1_000_000, max_parents=3, score="bdeu"),
     "alarm37_1e6_bic_mp4": dict(gen="alarm", N=1_000_000, max_parents=4, score="bic"),
     "hepar70_1e7_bdeu_mp3": dict(gen="hepar2", N=10_000_000, max_parents=3, score="bdeu"),
@@ -160,9 +160,10 @@ def spawn_ranks(n):
 
 def exhaustive_search_wallclock(engine, with_cpu):
     """Second half of the metric: wall-clock of the whole exhaustive search
-    (scores + subset DP + back-track, data resident) on BASELINE config 1 and on
-    a 20-variable case; the oracle's restatement of the reference search is timed
-    beside config 1 (the reference's own search cannot be compiled here)."""
+    (scores + subset DP + back-track, data resident) on the 8-variable ASIA-shaped
+    case (10^5 rows, <= 2 parents) and on a 20-variable case; the oracle's restatement
+    of the reference search is timed beside the former (the reference's own search
+    cannot be compiled here)."""
     from openbnsl_amd import synth
     res = []
     cases = [("asia8_1e5_bdeu_mp2", synth.asia(100_000, 0)[:2], 2),
@@ -191,7 +192,7 @@ def exhaustive_search_wallclock(engine, with_cpu):
 
 def simulated_annealing_wallclock(engine, data, with_cpu):
     """Wall-clock of simulated_annealing (a caller of the same table + score pair)
-    on the resident benchmark data set and on BASELINE config 1 data, where the
+    on the resident benchmark data set and on the 8-variable ASIA-shaped data, where the
     reference's own implementation (oracle/_ref) is timed beside it on a bounded
     number of steps."""
     from openbnsl_amd import synth
@@ -325,7 +326,7 @@ def main():
     # scores of this rank's shard of the top size (count the finite entries)
     top_scores_all = data.num_subsets(k_top) * k_top
     top_scores_rank = int(torch.isfinite(tables[k_top - 1]).sum().item())
-    # SURVEY's algorithmic bytes: N bytes per (child, parent set) score (one uint8
+    # algorithmic bytes: N bytes per (child, parent set) score (one uint8
     # column of N rows per score) x the scores one launch yields
     alg_bytes_per_launch = top_scores_rank * N / launches_per_step
     hbm_alg = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
@@ -392,7 +393,7 @@ def main():
                    "backend": (dist.get_backend() if exchange else None),
                    "sharding": f"subsets split over {world} rank(s) by cost; per-node bests all-gathered"},
         "roofline": roofline,
-        # the survey's fixed definition, kept beside the binding roofline: algorithmic
+        # the per-score definition above, kept beside the binding roofline: algorithmic
         # column bytes per second against the HBM peak (the row bitmaps are cache
         # resident and 8x denser than the columns, so this exceeds 1 by design)
         "roofline_hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
