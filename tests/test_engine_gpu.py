@@ -204,7 +204,7 @@ def test_error_behaviour(engine, golden):
 
 
 def test_alarm_shape_full_size_properties(engine):
-    """BASELINE config 2 at full size (37 vars, 1e6 rows, subsets up to 4):
+    """The benchmark configuration at full size (37 vars, 1e6 rows, subsets up to 4):
     sampled tables bit-exact vs the oracle, sampled scores within tolerance,
     and the size-independent invariant sum(counts) == N
     (reference: pytest/base/test_contingency_table.py:18-27)."""

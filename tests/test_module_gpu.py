@@ -72,7 +72,7 @@ def test_local_score_random_parent_sets(ob, seed):
 
 
 def test_exhaustive_search_asia_recovers_structure(ob, golden):
-    """BASELINE config 1 (ASIA, 8 vars, 1e5 rows, BDeu): the same edge list the
+    """The ASIA configuration (8 vars, 1e5 rows, BDeu): the same edge list the
     reference returned on this data set, for max_parents 2 and 3."""
     from openbnsl_amd import synth
     meta, _ = golden

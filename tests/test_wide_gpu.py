@@ -1,4 +1,4 @@
-"""GPU: data sets wider than 64 variables (BASELINE configs 4 and 5 are 70 and
+"""GPU: data sets wider than 64 variables (two benchmark configurations are 70 and
 128 variables wide; the reference's uint64 subset masks stop at 64,
 src/structure_learning/exhaustive_search.cpp:12,22-23).  Reduced row counts so
 that the oracle finishes in seconds; subset sizes as in those configs."""
