@@ -2053,7 +2053,11 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
         const char* e = std::getenv("OBNSL_MFMA_TILE");
         return e ? std::atoi(e) : 0;
       }();
-      if (big == 256 || (big == 0 && tiles.size() >= BIG_TILE_FROM)) {
+      static const size_t big_from = [] {
+        const char* e = std::getenv("OBNSL_BIG_TILE_FROM");
+        return e ? (size_t)std::atol(e) : BIG_TILE_FROM;
+      }();
+      if (big == 256 || (big == 0 && tiles.size() >= big_from)) {
         plan->tile = 256;
         make_tiles(256, tiles);
       }
@@ -2226,8 +2230,9 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   // (measured on the 37-variable workload, whole pass: one tile cut into ~64 units -- 16
   // units of ~64 steps when it runs beside a launch of many tiles, whose workgroup slots
   // it would take --, 17 tiles into ~384, more tiles into ~4096 units, at least two per
-  // tile and up to 16384 of ~256 steps (70 variables, 10^7 rows: 306 tiles, +5 % from 4096
-  // to 8192..16384 units) when the units add into tile images, ~896 when they add into the
+  // tile and up to 12288 of ~96 steps (70 variables, 10^7 rows: 306 tiles, +5 % from 4096
+  // to 8192..16384 units; 37 variables, five-variable tables: 759 tiles, +4 % from 4096 to
+  // 8192) when the units add into tile images, ~896 when they add into the
   // table with scattered atomics: short units pay their prologue and epilogue, long ones
   // leave CUs idle at the end of the launch)
   // split launches of 128 x 128 tiles add into tile images (up to IMAGE_MAX_BYTES of
@@ -2240,7 +2245,7 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
     return e ? (uint64_t)std::atoi(e) << 20 : IMAGE_MAX_BYTES;
   }();
   const uint64_t img_cells = (uint64_t)b->nitems * plan->tile * plan->tile;
-  const bool image_ok = plan->mfma && plan->tile == 128 && !no_image && b->nitems > 2 &&
+  const bool image_ok = plan->mfma && !no_image && b->nitems > 2 &&
                         img_cells * sizeof(uint32_t) <= image_max;
   const uint32_t want = want_env ? want_env
                         : !plan->mfma ? 8192u
@@ -2248,7 +2253,7 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
                                                             : want_tier(0))
                         : b->nitems <= 32 ? want_tier(1)
                         : image_ok ? std::max({want_tier(3), 2 * b->nitems,
-                                               (uint32_t)std::min<uint64_t>((uint64_t)b->nitems * steps_total / 256, 16384)})
+                                               (uint32_t)std::min<uint64_t>((uint64_t)b->nitems * steps_total / 96, 12288)})
                                    : want_tier(2);
   static const uint32_t min_sps = [] {
     const char* e = std::getenv("OBNSL_MIN_SPS");
@@ -2314,8 +2319,12 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   }
   HIP_TRY(hipGetLastError());
   if (image) {
-    hipLaunchKernelGGL(image_scatter_kernel<128>, dim3(b->nitems * (128 / 8)), dim3(256), 0, d->count_stream(),
-                       b->img.p, b->items.p, b->rows.p, b->nrows, table);
+    if (plan->tile == 256)
+      hipLaunchKernelGGL(image_scatter_kernel<256>, dim3(b->nitems * (256 / 8)), dim3(256), 0, d->count_stream(),
+                         b->img.p, b->items.p, b->rows.p, b->nrows, table);
+    else
+      hipLaunchKernelGGL(image_scatter_kernel<128>, dim3(b->nitems * (128 / 8)), dim3(256), 0, d->count_stream(),
+                         b->img.p, b->items.p, b->rows.p, b->nrows, table);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(ev.second, d->count_stream()));
