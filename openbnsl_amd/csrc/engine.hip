@@ -1226,22 +1226,37 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
     __syncthreads();
     // E(e): digit 0 = "any".  Within a pattern the counter index is the mixed-radix
     // number of the non-zero digits (radix r - 1, first variable most significant).
+    // Four cells per lane at a time: their counter loads are issued together, before
+    // any of them is stored (a store into LDS between them would order the loads).
     if (active) {
-      for (uint32_t cell = lane; cell < cells; cell += SC_LANES) {
-        uint32_t rem = cell, pat = 0, key = 0, mul = 1;
+      for (uint32_t cell0 = lane; cell0 < cells; cell0 += 4 * SC_LANES) {
+        uint32_t val[4];
 #pragma unroll
-        for (int i = KFAST - 1; i >= 0; --i) {
-          if (i >= (int)k) continue;
-          const uint32_t qt = fast_div(rem, inv_card[i]);
-          const uint32_t e = rem - qt * cards[i];
-          rem = qt;
-          if (e) {
-            pat |= 1u << i;
-            key += (e - 1) * mul;
-            mul *= cards[i] - 1;
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t cell = cell0 + u * SC_LANES;
+          val[u] = num_rows;
+          if (cell < cells) {
+            uint32_t rem = cell, pat = 0, key = 0, mul = 1;
+#pragma unroll
+            for (int i = KFAST - 1; i >= 0; --i) {
+              if (i >= (int)k) continue;
+              const uint32_t qt = fast_div(rem, inv_card[i]);
+              const uint32_t e = rem - qt * cards[i];
+              rem = qt;
+              if (e) {
+                pat |= 1u << i;
+                key += (e - 1) * mul;
+                mul *= cards[i] - 1;
+              }
+            }
+            if (pat) val[u] = sv[__popc(pat)].red[pat_base[pat] + key];
           }
         }
-        E[cell] = pat ? sv[__popc(pat)].red[pat_base[pat] + key] : num_rows;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t cell = cell0 + u * SC_LANES;
+          if (cell < cells) E[cell] = val[u];
+        }
       }
     }
     __syncthreads();
