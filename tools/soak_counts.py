@@ -1,0 +1,62 @@
+"""Development soak (GPU + oracle): random data shapes through the batch path -- every
+subset size up to kmax, sampled tables of the batch kernel's own counters and their
+scores against the oracle.  Prints one line per case and a summary.
+    python tools/soak_counts.py [cases] [first seed]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import oracle
+from openbnsl_amd import engine, synth
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = 0
+for seed in range(seed0, seed0 + cases):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(5, 44))
+    cards = rng.integers(2, 6, size=n).tolist()
+    N = int(rng.choice([97, 1000, 4097, 33_000, 70_001, 250_000, 1_000_003]))
+    kmax = int(rng.integers(2, 6)) if n <= 30 else int(rng.integers(2, 5))
+    kmax = min(kmax, n)
+    try:
+        codes, card, _, _ = synth.random_bn(cards, N, seed=seed)
+    except AssertionError:      # the generator insists on every state being observed
+        print(f"seed {seed}: n={n} N={N}: a state is unobserved, skipped", flush=True)
+        continue
+    d = engine.Data(codes, card)
+    worst, paths = 0.0, []
+    ok = True
+    kept = {}
+    for k in range(1, kmax + 1):
+        scores = d.score_all(k)
+        kept[k] = scores
+        paths.append(d.count_path(k))
+        for _ in range(6):
+            vs = sorted(rng.choice(n, size=k, replace=False).tolist())
+            want = oracle.count(codes, card, vs)
+            got = d.full_table_from_reduced(vs) if d.count_path(k) != "histogram" else d.count(vs)
+            if not np.array_equal(got, want):
+                ok = False
+                print("  COUNT MISMATCH", seed, k, vs, flush=True)
+            row = scores[engine.rank(vs)]
+            for ci in range(k):
+                w = oracle.local_score(want, card[vs], ci)
+                worst = max(worst, abs(row[ci] - w) / abs(w))
+    if worst > 1e-9:
+        ok = False
+    # a second and a third pass over fresh bitmaps (the tile images of the split launches
+    # are cleared by the pack in between): bit-identical scores, largest size first once
+    for order in (range(1, kmax + 1), range(kmax, 0, -1)):
+        d.pack()
+        for k in order:
+            if not np.array_equal(d.score_all(k), kept[k]):
+                ok = False
+                print("  PASS MISMATCH", seed, k, flush=True)
+    bad += not ok
+    print(f"seed {seed}: n={n} N={N} kmax={kmax} paths={paths} worst rel {worst:.2e} {'ok' if ok else 'FAIL'}", flush=True)
+    d.close()
+print("cases", cases, "failed", bad)
+sys.exit(1 if bad else 0)
