@@ -1,6 +1,7 @@
 """Development soak (GPU + oracle): random data shapes through the batch path -- every
 subset size up to kmax, sampled tables of the batch kernel's own counters and their
-scores against the oracle.  Prints one line per case and a summary.
+scores against the oracle, repeated passes, and the same pass in shards.  Prints one line
+per case and a summary.
     python tools/soak_counts.py [cases] [first seed]"""
 import os
 import sys
@@ -55,6 +56,29 @@ for seed in range(seed0, seed0 + cases):
             if not np.array_equal(d.score_all(k), kept[k]):
                 ok = False
                 print("  PASS MISMATCH", seed, k, flush=True)
+    # the same sizes in shards (a random world size, one data set object per rank, lower
+    # sizes first as a pass does): every score exactly once, bit-identical to the whole pass
+    import torch
+    world = int(rng.choice([2, 3, 5, 8]))
+    merged = {k: torch.full((kept[k].size,), float("-inf"), dtype=torch.float64, device="cuda")
+              for k in kept}
+    for r in range(world):
+        dr = engine.Data(codes, card)
+        dr.precount(kmax, r, world)
+        for k in range(1, kmax + 1):
+            buf = torch.full((kept[k].size,), float("-inf"), dtype=torch.float64, device="cuda")
+            dr.score_all_device(k, buf.data_ptr(), shard=r, num_shards=world)
+            torch.cuda.synchronize()
+            fin = torch.isfinite(buf)
+            if bool((fin & torch.isfinite(merged[k])).any()):
+                ok = False
+                print("  SHARD OVERLAP", seed, k, r, world, flush=True)
+            merged[k] = torch.where(fin, buf, merged[k])
+        dr.close()
+    for k in kept:
+        if not np.array_equal(merged[k].cpu().numpy(), kept[k].reshape(-1)):
+            ok = False
+            print("  SHARD MISMATCH", seed, k, world, flush=True)
     bad += not ok
     print(f"seed {seed}: n={n} N={N} kmax={kmax} paths={paths} worst rel {worst:.2e} {'ok' if ok else 'FAIL'}", flush=True)
     d.close()
