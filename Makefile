@@ -20,10 +20,34 @@ else
 all: $(ENGINE) oracle
 endif
 
-ENGINE_SRC := openbnsl_amd/csrc/engine.hip openbnsl_amd/csrc/group.hip openbnsl_amd/csrc/anneal.cpp openbnsl_amd/csrc/score_file.cpp
-$(ENGINE): $(ENGINE_SRC) openbnsl_amd/csrc/engine_internal.h include/obnsl_engine.h
+CSRC := openbnsl_amd/csrc
+ENGINE_SRC := $(CSRC)/abi.hip $(CSRC)/planner.hip $(CSRC)/gemm_mfma.hip $(CSRC)/gemm_valu.hip \
+              $(CSRC)/kernels_count.hip $(CSRC)/kernels_score.hip $(CSRC)/kernels_search.hip \
+              $(CSRC)/group.hip $(CSRC)/env.cpp $(CSRC)/anneal.cpp $(CSRC)/score_file.cpp
+ENGINE_HDR := $(CSRC)/engine_internal.h $(CSRC)/engine_types.h $(CSRC)/engine_state.h include/obnsl_engine.h
+ENGINE_OBJ := $(patsubst $(CSRC)/%,build/engine/%.o,$(ENGINE_SRC))
+PROBE_OBJ := $(patsubst $(CSRC)/%,build/probes/%.o,$(ENGINE_SRC))
+# the same library with the timing probes compiled in (wrong counts by construction when one
+# is switched on): loaded only by tools/, through OBNSL_ENGINE_LIB
+PROBE_LIB := tools/bin/libobnsl_engine_probes.so
+
+build/engine/%.o: $(CSRC)/% $(ENGINE_HDR)
+	mkdir -p build/engine
+	$(HIPCC) $(HIPFLAGS) -I$(CSRC) -pthread -c $< -o $@
+
+build/probes/%.o: $(CSRC)/% $(ENGINE_HDR)
+	mkdir -p build/probes
+	$(HIPCC) $(HIPFLAGS) -DOBNSL_PROBES -I$(CSRC) -pthread -c $< -o $@
+
+$(ENGINE): $(ENGINE_OBJ) $(CSRC)/exports.map
 	mkdir -p openbnsl_amd/lib
-	$(HIPCC) $(HIPFLAGS) -Iopenbnsl_amd/csrc -pthread -shared $(ENGINE_SRC) -ldl -o $@
+	$(HIPCC) --offload-arch=gfx950 -fPIC -pthread -shared $(ENGINE_OBJ) -ldl -Wl,--version-script=$(CSRC)/exports.map -o $@
+
+$(PROBE_LIB): $(PROBE_OBJ)
+	mkdir -p tools/bin
+	$(HIPCC) --offload-arch=gfx950 -fPIC -pthread -shared $(PROBE_OBJ) -ldl -Wl,--version-script=$(CSRC)/exports.map -o $@
+
+probes: $(PROBE_LIB)
 
 $(PYMOD): $(HOST_SRC) $(HOST_HDR) $(ENGINE)
 	g++ -O2 -std=c++17 -fPIC -shared -fvisibility=hidden -Wall -Iinclude -Iopenbnsl_amd/host \
@@ -34,7 +58,8 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(ENGINE) $(PYMOD)
+	rm -f $(ENGINE) $(PYMOD) $(PROBE_LIB)
+	rm -rf build/engine build/probes
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean probes

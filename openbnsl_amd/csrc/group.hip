@@ -41,17 +41,17 @@ namespace {
 
 using obnsl_internal::fail;
 
-#define HIP_TRY(expr)                                                                  \
-  do {                                                                                 \
-    hipError_t e_ = (expr);                                                            \
-    if (e_ != hipSuccess)                                                              \
-      return fail(OBNSL_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-  } while (0)
-#define OB_TRY(expr)                   \
-  do {                                 \
-    obnsl_status s_ = (expr);          \
-    if (s_ != OBNSL_OK) return s_;     \
-  } while (0)
+// Restores the caller's current HIP device when a group call returns: every call
+// below moves through the group's devices with hipSetDevice.
+struct DeviceGuard {
+  int saved = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+  }
+  ~DeviceGuard() {
+    if (saved >= 0) (void)hipSetDevice(saved);
+  }
+};
 
 // ---- the few RCCL entry points used, bound at run time
 typedef void* nccl_comm_t;
@@ -157,6 +157,23 @@ obnsl_status nccl_check(int rc, const char* what) {
   return fail(OBNSL_ERR_RUNTIME, std::string(what) + ": " + msg);
 }
 
+// One collective per rank between ncclGroupStart and ncclGroupEnd, from this one
+// thread.  The group is always ended, also when a call inside it fails (a thread
+// left inside an open group defers every later collective); the first error wins.
+template <class PerRank>
+obnsl_status grouped(size_t world, PerRank per_rank) {
+  OB_TRY(nccl_check(rccl().GroupStart(), "ncclGroupStart"));
+  obnsl_status first = OBNSL_OK;
+  std::string first_msg;
+  for (size_t r = 0; r < world && first == OBNSL_OK; ++r) {
+    first = per_rank(r);
+    if (first != OBNSL_OK) first_msg = obnsl_last_error();
+  }
+  const obnsl_status end = nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+  if (first != OBNSL_OK) return fail(first, first_msg);
+  return end;
+}
+
 obnsl_status ensure_tables(obnsl_group* g, uint32_t kmax) {
   if (kmax <= g->tables_for) return OBNSL_OK;
   for (Rank& r : g->ranks) {
@@ -199,11 +216,10 @@ obnsl_status all_reduce_sum_u32(obnsl_group* g, const std::vector<uint32_t*>& pt
   const size_t W = g->ranks.size();
   if (W == 1 && !g->use_rccl) return OBNSL_OK;
   if (g->use_rccl) {
-    OB_TRY(nccl_check(rccl().GroupStart(), "ncclGroupStart"));
-    for (size_t r = 0; r < W; ++r)
-      OB_TRY(nccl_check(rccl().AllReduce(ptr[r], ptr[r], words, kU32, kSum, g->ranks[r].comm, g->ranks[r].stream),
-                        "ncclAllReduce"));
-    return nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    return grouped(W, [&](size_t r) {
+      return nccl_check(rccl().AllReduce(ptr[r], ptr[r], words, kU32, kSum, g->ranks[r].comm, g->ranks[r].stream),
+                        "ncclAllReduce");
+    });
   }
   // copy exchange: rank 0 adds the others' tables into its own, then hands the sum back
   OB_TRY(fan_in(g));
@@ -233,11 +249,10 @@ obnsl_status all_gather_f64(obnsl_group* g, const std::vector<double*>& send, co
                             uint64_t count) {
   const size_t W = g->ranks.size();
   if (g->use_rccl) {
-    OB_TRY(nccl_check(rccl().GroupStart(), "ncclGroupStart"));
-    for (size_t r = 0; r < W; ++r)
-      OB_TRY(nccl_check(rccl().AllGather(send[r], recv[r], count, kF64, g->ranks[r].comm, g->ranks[r].stream),
-                        "ncclAllGather"));
-    return nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    return grouped(W, [&](size_t r) {
+      return nccl_check(rccl().AllGather(send[r], recv[r], count, kF64, g->ranks[r].comm, g->ranks[r].stream),
+                        "ncclAllGather");
+    });
   }
   OB_TRY(fan_in(g));
   Rank& r0 = g->ranks[0];
@@ -256,11 +271,10 @@ obnsl_status all_reduce_max_f64(obnsl_group* g, const std::vector<double*>& ptr,
   const size_t W = g->ranks.size();
   if (W == 1 && !g->use_rccl) return OBNSL_OK;
   if (g->use_rccl) {
-    OB_TRY(nccl_check(rccl().GroupStart(), "ncclGroupStart"));
-    for (size_t r = 0; r < W; ++r)
-      OB_TRY(nccl_check(rccl().AllReduce(ptr[r], ptr[r], count, kF64, kMax, g->ranks[r].comm, g->ranks[r].stream),
-                        "ncclAllReduce"));
-    return nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    return grouped(W, [&](size_t r) {
+      return nccl_check(rccl().AllReduce(ptr[r], ptr[r], count, kF64, kMax, g->ranks[r].comm, g->ranks[r].stream),
+                        "ncclAllReduce");
+    });
   }
   OB_TRY(fan_in(g));
   Rank& r0 = g->ranks[0];
@@ -337,6 +351,7 @@ extern "C" {
 obnsl_status obnsl_group_create(const uint8_t* codes, uint64_t num_rows, uint64_t col_stride,
                                 uint32_t num_vars, const uint32_t* cardinalities, const int* devices,
                                 uint32_t num_devices, obnsl_group** out) {
+  DeviceGuard device_guard;
   if (!out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "out is null");
   *out = nullptr;
   if (!devices || num_devices == 0 || num_devices > 64)
@@ -388,6 +403,7 @@ obnsl_status obnsl_group_create(const uint8_t* codes, uint64_t num_rows, uint64_
 }
 
 obnsl_status obnsl_group_destroy(obnsl_group* g) {
+  DeviceGuard device_guard;
   delete g;
   return OBNSL_OK;
 }
@@ -402,6 +418,7 @@ obnsl_status obnsl_group_info(const obnsl_group* g, uint32_t* num_devices, int* 
 obnsl_status obnsl_group_best_parents(obnsl_group* g, obnsl_score_kind kind, double ess,
                                       uint32_t max_parents, int repack, double* best_score,
                                       uint32_t* best_size, uint64_t* best_rank) {
+  DeviceGuard device_guard;
   if (!g || !best_score || !best_size || !best_rank) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
   if (max_parents + 1 > g->n) return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   const uint32_t W = (uint32_t)g->ranks.size(), kmax = max_parents + 1;
@@ -439,6 +456,7 @@ obnsl_status obnsl_group_best_parents(obnsl_group* g, obnsl_score_kind kind, dou
 
 obnsl_status obnsl_group_score_tables(obnsl_group* g, obnsl_score_kind kind, double ess,
                                       uint32_t max_parents, int repack, double* const* tables_out) {
+  DeviceGuard device_guard;
   if (!g || !tables_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
   if (max_parents + 1 > g->n) return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   const uint32_t W = (uint32_t)g->ranks.size(), kmax = max_parents + 1;
@@ -464,6 +482,7 @@ obnsl_status obnsl_group_score_tables(obnsl_group* g, obnsl_score_kind kind, dou
 obnsl_status obnsl_group_exhaustive_search(obnsl_group* g, obnsl_score_kind kind, double ess,
                                            uint32_t max_parents, uint64_t* parents_out,
                                            double* total_score_out) {
+  DeviceGuard device_guard;
   if (!g || !parents_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
   // reference: exhaustive_search.cpp:18-23
   if (max_parents > g->n - 1) return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
