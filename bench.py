@@ -434,7 +434,7 @@ def main():
                                      "frac": (hbm_alg / HBM_PEAK_GBS) if hbm_alg else None,
                                      "algorithmic_bytes_per_launch": alg_bytes_per_launch},
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.only_hot_path:
         out["two_data_sets_in_flight"] = two_data_sets_in_flight(torch, HotPath, hot, codes, card, mp, kind,
                                                                    dev_index, args.steps, args.warmup)
     if rank == 0 and world == 1 and not args.only_hot_path:

@@ -216,6 +216,22 @@ obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_sco
 obnsl_status obnsl_best_parents_device_noalloc(obnsl_data* d, const double* const* d_scores,
                                                uint32_t max_parents, double* d_out);
 
+/* The scoring phase of exhaustive_search
+ * (src/structure_learning/exhaustive_search.cpp:47-73) for EVERY subset size
+ * 1..max_parents+1 in one call, followed by the per-node reduction of
+ * obnsl_best_parents_device: the same outputs as one obnsl_score_all per size
+ * (d_tables[k-1] = device table of subset size k; shard / num_shards as there)
+ * and, when d_best_out is not null, one obnsl_best_parents_device (3 * num_vars
+ * doubles, device).  Where every size goes through the bit-plane contraction and
+ * max_parents + 1 <= 5, the sizes share their launches (one evaluates every
+ * table's functional, one turns them into scores and finds each node's best);
+ * otherwise the call is the per-size calls in a row.  The counts come from the
+ * current row bitmaps (obnsl_precount / obnsl_precount_sharded first when the
+ * counting should overlap or is sharded).  Asynchronous on the data set's stream. */
+obnsl_status obnsl_score_pass(obnsl_data* d, obnsl_score_kind kind, double ess, uint32_t max_parents,
+                              uint32_t shard, uint32_t num_shards, double* const* d_tables,
+                              double* d_best_out);
+
 /* The combine step after ranks have all-gathered their obnsl_best_parents_device
  * records: d_parts (device) = `world` records of 3 * num_vars doubles, rank
  * after rank; d_out (device, 3 * num_vars doubles) = per node the best of them

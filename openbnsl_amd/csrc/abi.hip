@@ -442,41 +442,12 @@ obnsl_status obnsl_score_subsets(obnsl_data* d, obnsl_score_kind kind, double es
   return OBNSL_OK;
 }
 
-// `keys`: 2 n words of device memory, keys [0, n), ids [n, 2n); null = the data
-// set's own buffer (allocated on first use).
-static obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_scores,
-                                       uint32_t max_parents, unsigned long long* keys = nullptr) {
-  if (max_parents + 1 > (uint32_t)KMAX || max_parents + 1 > d->n)
-    return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
-  obnsl_status st = set_device(d->device);
-  if (st != OBNSL_OK) return st;
-  if (!keys) {
-    HIP_TRY(d->best_key.ensure(2 * (size_t)d->n));
-    keys = d->best_key.p;
-  }
-  unsigned long long* key = keys;
-  unsigned long long* id = keys + d->n;
-  launch_best_init(d->stream, key, id, d->n);
-  BestArgs args;
-  std::memset(&args, 0, sizeof(args));
-  args.kmax = max_parents + 1;
-  for (uint32_t k = 1; k <= max_parents + 1; ++k) {
-    const uint64_t nsub = binom_host(d->n, k);
-    args.scores[k - 1] = d_scores[k - 1];
-    args.nsubsets[k - 1] = nsub;
-    args.block_start[k] = args.block_start[k - 1] + (uint32_t)std::min<uint64_t>((nsub + 255) / 256, 512);
-  }
-  for (int pass = 0; pass < 2; ++pass) launch_best_parents(d->stream, args, d->n, d->d_binom.p, key, id, pass);
-  HIP_TRY(hipGetLastError());
-  return OBNSL_OK;
-}
-
 obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
                                 uint32_t max_parents, double* best_score,
                                 uint32_t* best_size, uint64_t* best_rank) {
   if (!d || !d_scores || !best_score || !best_size || !best_rank)
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
-  obnsl_status st = queue_best_parents(d, d_scores, max_parents);
+  obnsl_status st = queue_best_parents(d, d_scores, max_parents, nullptr, false);
   if (st != OBNSL_OK) return st;
   std::vector<unsigned long long> hboth(2 * (size_t)d->n);
   HIP_TRY(hipMemcpyAsync(hboth.data(), d->best_key.p, hboth.size() * 8, hipMemcpyDeviceToHost, d->stream));
@@ -504,7 +475,7 @@ obnsl_status obnsl_best_parents(obnsl_data* d, const double* const* d_scores,
 obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_scores,
                                        uint32_t max_parents, double* d_out) {
   if (!d || !d_scores || !d_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
-  obnsl_status st = queue_best_parents(d, d_scores, max_parents);
+  obnsl_status st = queue_best_parents(d, d_scores, max_parents, nullptr, false);
   if (st != OBNSL_OK) return st;
   launch_best_decode(d->stream, d->best_key.p, d->best_key.p + d->n, d->n, d_out);
   HIP_TRY(hipGetLastError());
@@ -525,11 +496,17 @@ obnsl_status obnsl_best_parents_device_noalloc(obnsl_data* d, const double* cons
   if (!ptr) return fail(OBNSL_ERR_RUNTIME, "no scratch address for this device");
   // the arg-max kernels start from best_init_kernel's fill of [0, 2 n): what an
   // earlier (possibly larger) call left in the array is never read
-  obnsl_status st = queue_best_parents(d, d_scores, max_parents, ptr);
+  obnsl_status st = queue_best_parents(d, d_scores, max_parents, ptr, false);
   if (st != OBNSL_OK) return st;
   launch_best_decode(d->stream, ptr, ptr + d->n, d->n, d_out);
   HIP_TRY(hipGetLastError());
   return OBNSL_OK;
+}
+
+obnsl_status obnsl_score_pass(obnsl_data* d, obnsl_score_kind kind, double ess, uint32_t max_parents,
+                              uint32_t shard, uint32_t num_shards, double* const* d_tables,
+                              double* d_best_out) {
+  return score_pass_impl(d, kind, ess, max_parents, shard, num_shards, d_tables, d_best_out, nullptr);
 }
 
 obnsl_status obnsl_combine_best_device(obnsl_data* d, const double* d_parts, uint32_t world,

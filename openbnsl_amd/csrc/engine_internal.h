@@ -34,10 +34,13 @@ struct Env {
   bool no_reduced = false;        // OBNSL_NO_REDUCED: count every state (no inclusion-exclusion)
   bool force_hist = false;        // OBNSL_FORCE_HIST: per-row histogram path for every size
   bool force_bitgemm = false;     // OBNSL_FORCE_BITGEMM: bit-plane contraction wherever it is possible
+  bool no_fused = false;          // OBNSL_NO_FUSED: one scorer launch per subset size, never the fused launches
   bool runs = true;               // OBNSL_NO_RUNS clears it: one work unit per workgroup, never persistent workgroups
   std::vector<double> run_phases; // OBNSL_RUN_PHASES=80,12,8: shares (percent) of a launch per phase of runs
   std::vector<uint32_t> run_pieces;  // OBNSL_RUN_PIECES=1,1,1: runs per workgroup slot in each phase
-  bool runs_persistent = false;   // OBNSL_RUNS_PERSISTENT: launch only as many workgroups as the chip holds; later runs from a queue
+  bool together = true;           // OBNSL_NO_TOGETHER clears it: one count launch per subset size, never one for all
+  std::vector<double> together_phases;    // OBNSL_TOGETHER_PHASES / _PIECES: phases of the launch over all sizes
+  std::vector<uint32_t> together_pieces;
   uint32_t runs_max_steps = 1024; // OBNSL_RUNS_MAX_STEPS: longest launch (contraction steps per slot) that takes the form
   int probe = 0;                  // OBNSL_PROBE=<bits>: timing probes; read only by builds with -DOBNSL_PROBES
 };

@@ -60,6 +60,8 @@ struct Batch {
   uint32_t nruns = 0;
   bool units_split = false;            // some tile is cut into several units (atomics needed)
   std::vector<uint64_t> h_tbl_start;   // first table of every row group (host copy)
+  std::vector<uint64_t> h_rank_part;   // ... its part of the colex rank, its number of column groups
+  std::vector<uint32_t> h_ncolgroups;
   DevBuf<uint32_t> wg_rg;              // scorer: row group of each workgroup's first table ...
   uint32_t wg_rg_tpw = 0;              // ... for this many tables per workgroup
   DevBuf<uint32_t> img;                // split launches: one row-major tile x tile image per item
@@ -101,9 +103,27 @@ struct Plan {
   uint64_t total_items = 0;
   // per-table functional G[colex rank] of this plan's tables (see score_reduced_kernel)
   DevBuf<double> G;
+  DevBuf<uint8_t> own_mask;     // sharded plan: 1 per colex rank of a table this shard scores
+  bool own_mask_built = false;
   uint64_t g_epoch = 0;
   int g_kind = -1;
   double g_ess = 0.0;
+};
+
+// One subset size's share of a count launch over several sizes.
+struct CountPart {
+  Plan* plan;
+  Batch* b;
+  uint32_t* table;     // where the counts go (the plan's table, or a slice of the whole plan's)
+  bool prezeroed;      // the table is already clear for this launch
+  bool image = false;  // (set by the launch) counted through tile images
+};
+// The cached work list of such a launch (runs of units over the tiles of all its batches).
+struct TogetherLaunch {
+  std::vector<const Batch*> batches;
+  uint32_t steps = 0, nruns = 0, nworkgroups = 0;
+  DevBuf<MfmaUnit> units;
+  DevBuf<uint32_t> unit_start;
 };
 
 }  // namespace obnsl_internal
@@ -134,6 +154,7 @@ struct obnsl_data {
   int count_lane = -1;                                // launch_count targets side[count_lane] (-1: `stream`)
   bool beside_large = false;                          // the launches of obnsl_precount run beside one of many tiles
   std::vector<obnsl_internal::Plan*> lane_plans[2];   // plans whose counts a lane is still producing
+  std::vector<std::unique_ptr<obnsl_internal::TogetherLaunch>> together;  // launches over several subset sizes
   // per ess: lgamma(ess / c) for c = 1..REDUCED_MAX_CELLS (index c), from the host's libm
   std::map<double, std::unique_ptr<obnsl_internal::DevBuf<double>>> lg_alpha;
   hipStream_t count_stream() const {
@@ -169,6 +190,8 @@ namespace obnsl_internal {
 obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nshards, bool reduced, Plan** out);
 obnsl_status resolve_events(obnsl_data* d);
 obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts, bool prezeroed = false);
+bool can_count_together(const obnsl_data* d, const std::vector<CountPart>& parts);
+obnsl_status launch_count_together(obnsl_data* d, std::vector<CountPart>& parts);
 obnsl_status join_lane(obnsl_data* d, int lane);
 obnsl_status join_side(obnsl_data* d);
 obnsl_status ensure_counts(obnsl_data* d, Plan* plan);
@@ -183,6 +206,11 @@ obnsl_status run_pack(obnsl_data* d, uint32_t* bad_code = nullptr);
 obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_t num_shards, bool shard_lower,
                            uint32_t* sum_size_out, uint64_t* sum_cells_out);
 obnsl_status whole_table(obnsl_data* d, uint32_t k, Plan** out);
+obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, uint32_t max_parents, uint32_t shard,
+                             uint32_t num_shards, double* const* d_tables, double* d_best_out,
+                             unsigned long long* keys);
+obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_scores, uint32_t max_parents,
+                                unsigned long long* keys, bool skip_first_pass);
 uint64_t whole_below(const Plan* p);
 obnsl_status score_all_impl(obnsl_data* d, obnsl_score_kind kind, double ess, uint32_t k, uint32_t shard,
                             uint32_t num_shards, double* scores_out, int out_on_device);
@@ -240,6 +268,8 @@ struct ReducedScorerArgs {
   unsigned long long* best_key;   // per-node running maximum of the ordered scores (null: not kept)
 };
 void launch_score_reduced(hipStream_t s, uint32_t k, uint32_t parts, uint32_t grid, const ReducedScorerArgs& a);
+void launch_functional_all(hipStream_t s, uint32_t grid, size_t lds_bytes, const FunctionalAllArgs& a);
+void launch_scores_best(hipStream_t s, const ScoresAllArgs& a);
 // kernels_search.hip
 void launch_best_init(hipStream_t s, unsigned long long* keys, unsigned long long* ids, uint32_t n);
 void launch_best_parents(hipStream_t s, const BestArgs& args, uint32_t n, const uint64_t* binom,

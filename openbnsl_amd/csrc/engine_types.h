@@ -74,7 +74,9 @@ struct ZeroList {
 struct MfmaUnit {
   uint32_t row_tile, col_tile, step_lo, step_hi;
   uint32_t blocks;   // 32-column blocks of the tile that hold a valid column (>= 1)
-  uint32_t tile;     // index of the tile in the launch's tile list (its image)
+  uint32_t tile;     // index of the tile in its part's tile list (its image)
+  uint32_t part;     // part of the launch (0 unless one launch counts several subset sizes)
+  uint32_t pad_;
 };
 
 // Operands of one contraction launch.
@@ -87,6 +89,23 @@ struct GemmOperands {
   uint32_t ncols_total;
 };
 
+// One launch can count several subset sizes ("parts"): the rows, columns and count
+// table (or tile images) of each part after the first, which the kernel's own
+// arguments describe.  Smaller sizes have fewer variables per row / column than the
+// kernel's KR / KC; their descriptors name the all-ones bitmap in the unused places.
+constexpr int GEMM_MAX_PARTS = 5;
+struct GemmPart {
+  const RowDesc* rows;
+  const ColDesc* cols;
+  uint32_t* counts;
+  uint32_t nrows, ncols_total;
+  int image;    // counts = tile images of the part (else its count table, added into)
+  int pad_;
+};
+struct GemmParts {
+  GemmPart p[GEMM_MAX_PARTS - 1];
+};
+
 // Work list of one matrix-core launch.  unit_start == nullptr: workgroup w works on
 // units[w] (nworkgroups units).  Otherwise run r is units[unit_start[r] ..
 // unit_start[r + 1]), r < nruns; nworkgroups persistent workgroups start with runs
@@ -97,6 +116,7 @@ struct MfmaLaunch {
   uint32_t nruns;
   uint32_t* queue;
   uint32_t nworkgroups;
+  GemmParts extra;   // parts 1.. of a launch over several subset sizes (runs only)
   uint64_t* trace;   // probe builds only
 };
 
@@ -116,6 +136,44 @@ struct SizeView {            // where the reduced tables of one subset size live
 };
 struct ReducedViews {
   SizeView v[KFAST + 1];
+};
+
+// The fused scoring launches (every subset size at once) serve sizes up to this one.
+constexpr int FUSED_KMAX = 5;
+struct FunctionalSizeArgs {       // one subset size of functional_all_kernel
+  const RowGroupDesc* rgs;
+  const uint32_t* wg_rg;          // row group of each workgroup's first table
+  double* G;                      // out: functional by colex rank
+  uint64_t ntables;
+  uint32_t tables_per_wg, parts, e_stride;
+  uint32_t block_start;           // first workgroup of this size
+};
+struct FunctionalAllArgs {
+  ReducedViews views;
+  FunctionalSizeArgs size[FUSED_KMAX + 1];   // by subset size, 1..kmax
+  uint32_t kmax;
+  const uint32_t* card;
+  const uint64_t* binom;
+  uint32_t num_rows;
+  int kind;
+  double ess;
+  const double* lg_alpha;
+  unsigned long long* best_key;   // keys [0, n), ids [n, 2 n): reset by workgroup 0 (null: none)
+  uint32_t n;
+};
+struct ScoresAllArgs {            // scores_best_kernel
+  const double* G[FUSED_KMAX + 1];   // G[k]: functional of size k by colex rank; G[0]: unused (g0)
+  double* scores[FUSED_KMAX + 1];    // scores[k]: table of subset size k
+  const uint8_t* mask[FUSED_KMAX + 1];  // mask[k][rank] != 0: this shard scores the table (null: all)
+  uint64_t nsubsets[FUSED_KMAX + 1];
+  uint32_t block_start[FUSED_KMAX + 2];
+  uint32_t kmax;
+  double g0;                      // functional of the empty table
+  const uint32_t* card;
+  const uint64_t* binom;
+  uint32_t n, num_rows;
+  int kind;
+  unsigned long long* best_key;   // per-node maximum of the ordered scores (null: not kept)
 };
 
 struct BestArgs {                 // every subset size in one launch

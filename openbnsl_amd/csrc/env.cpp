@@ -17,10 +17,12 @@
 //   OBNSL_NO_REDUCED         count every state with the contraction (no inclusion-exclusion in the scorer)
 //   OBNSL_FORCE_HIST         per-row histogram path for every subset size
 //   OBNSL_FORCE_BITGEMM      bit-plane contraction wherever it can run
+//   OBNSL_NO_FUSED           one scorer launch per subset size instead of the launches that serve every size
 //   OBNSL_NO_RUNS            one work unit per workgroup, never persistent workgroups over runs of units
 //   OBNSL_RUN_PHASES=a,b,..  shares (percent) of such a launch per phase of runs (default 80,12,8)
 //   OBNSL_RUN_PIECES=a,b,..  runs per workgroup slot in each phase (default 1,1,1)
-//   OBNSL_RUNS_PERSISTENT    launch only as many workgroups as the chip holds; the later runs come from a queue
+//   OBNSL_NO_TOGETHER        one count launch per subset size, never one persistent launch for all sizes
+//   OBNSL_TOGETHER_PHASES=.. / OBNSL_TOGETHER_PIECES=..  phases of that launch (default 65,15,10,10 / 1,1,1,2)
 //   OBNSL_RUNS_MAX_STEPS=n   longest launch, in contraction steps per workgroup slot, that takes the form
 //   OBNSL_PROBE=<bits>       timing probes; honoured only by a library built with -DOBNSL_PROBES
 //
@@ -45,6 +47,44 @@ long number(const char* name, long dflt) {
   char* end = nullptr;
   const long v = std::strtol(e, &end, 10);
   return (end && *end == '\0') ? v : dflt;
+}
+
+// "a,b,c" as shares (percent) that sum to 100, or empty
+std::vector<double> shares(const char* name) {
+  std::vector<double> v;
+  const char* e = std::getenv(name);
+  if (!e) return v;
+  double sum = 0.0;
+  const char* p = e;
+  while (*p) {
+    char* end = nullptr;
+    const double f = std::strtod(p, &end);
+    if (end == p || !(f > 0.0)) return {};
+    v.push_back(f / 100.0);
+    sum += f / 100.0;
+    if (*end == ',') p = end + 1;
+    else if (*end == '\0') break;
+    else return {};
+  }
+  if (v.empty() || sum < 0.99 || sum > 1.01) return {};
+  return v;
+}
+std::vector<uint32_t> counts_list(const char* name, size_t want) {
+  std::vector<uint32_t> v;
+  const char* e = std::getenv(name);
+  if (!e) return v;
+  const char* p = e;
+  while (*p) {
+    char* end = nullptr;
+    const long f = std::strtol(p, &end, 10);
+    if (end == p || f < 1 || f > 64) return {};
+    v.push_back((uint32_t)f);
+    if (*end == ',') p = end + 1;
+    else if (*end == '\0') break;
+    else return {};
+  }
+  if (v.size() != want) return {};
+  return v;
 }
 
 Env read_env() {
@@ -78,41 +118,31 @@ Env read_env() {
   x.no_reduced = flag("OBNSL_NO_REDUCED");
   x.force_hist = flag("OBNSL_FORCE_HIST");
   x.force_bitgemm = flag("OBNSL_FORCE_BITGEMM");
+  x.no_fused = flag("OBNSL_NO_FUSED");
   x.runs = !flag("OBNSL_NO_RUNS");
-  x.runs_persistent = flag("OBNSL_RUNS_PERSISTENT");
   x.run_phases = {0.80, 0.12, 0.08};
   x.run_pieces = {1, 1, 1};
   x.runs_max_steps = (uint32_t)number("OBNSL_RUNS_MAX_STEPS", 1024);
-  if (const char* e = std::getenv("OBNSL_RUN_PHASES")) {
-    std::vector<double> v;
-    double sum = 0.0;
-    const char* p = e;
-    while (*p) {
-      char* end = nullptr;
-      const double f = std::strtod(p, &end);
-      if (end == p || !(f > 0.0)) break;
-      v.push_back(f / 100.0);
-      sum += f / 100.0;
-      p = *end == ',' ? end + 1 : end;
-      if (*end != ',' && *end != '\0') break;
+  {
+    const std::vector<double> ph = shares("OBNSL_RUN_PHASES");
+    if (!ph.empty()) {
+      x.run_phases = ph;
+      x.run_pieces.assign(ph.size(), 1);
     }
-    if (!v.empty() && sum > 0.99 && sum < 1.01) {
-      x.run_phases = v;
-      x.run_pieces.assign(v.size(), 1);
-    }
+    const std::vector<uint32_t> pc = counts_list("OBNSL_RUN_PIECES", x.run_phases.size());
+    if (!pc.empty()) x.run_pieces = pc;
   }
-  if (const char* e = std::getenv("OBNSL_RUN_PIECES")) {
-    std::vector<uint32_t> v;
-    const char* p = e;
-    while (*p) {
-      char* end = nullptr;
-      const long f = std::strtol(p, &end, 10);
-      if (end == p || f < 1 || f > 64) break;
-      v.push_back((uint32_t)f);
-      p = *end == ',' ? end + 1 : end;
-      if (*end != ',' && *end != '\0') break;
+  x.together = !flag("OBNSL_NO_TOGETHER");
+  x.together_phases = {0.65, 0.15, 0.10, 0.10};
+  x.together_pieces = {1, 1, 1, 2};
+  {
+    const std::vector<double> ph = shares("OBNSL_TOGETHER_PHASES");
+    if (!ph.empty()) {
+      x.together_phases = ph;
+      x.together_pieces.assign(ph.size(), 1);
     }
-    if (v.size() == x.run_phases.size()) x.run_pieces = v;
+    const std::vector<uint32_t> pc = counts_list("OBNSL_TOGETHER_PIECES", x.together_phases.size());
+    if (!pc.empty()) x.together_pieces = pc;
   }
 #ifdef OBNSL_PROBES
   x.probe = (int)number("OBNSL_PROBE", 0);

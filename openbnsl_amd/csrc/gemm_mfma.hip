@@ -481,7 +481,7 @@ __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void b
     const uint32_t* __restrict__ planes, uint32_t wp, const RowDesc* __restrict__ rows,
     uint32_t nrows, const ColDesc* __restrict__ cols, uint32_t ncols_total,
     const MfmaUnit* __restrict__ units, const uint32_t* __restrict__ unit_start, uint32_t nruns,
-    uint32_t* __restrict__ queue, uint32_t* __restrict__ counts, int flags
+    uint32_t* __restrict__ queue, uint32_t* __restrict__ counts, int flags, GemmParts extra
 #ifdef OBNSL_PROBES
     , uint64_t* __restrict__ trace
 #endif
@@ -499,16 +499,32 @@ __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void b
 #endif
   constexpr uint32_t JFULL = TB / 32;
 #define OBNSL_MFMA_BODY(NA, NB)                                                                          \
-  mfma_tile_body<KR, KC, NA, NB, TB>(smem, planes, wp, rows, nrows, cols, ncols_total, row0, col0, counts, \
-                                     u.step_lo, u.step_hi, atomics, image, probe)
+  mfma_tile_body<KR, KC, NA, NB, TB>(smem, planes, wp, p_rows, p_nrows, p_cols, p_ncols, row0, col0,      \
+                                     p_counts, u.step_lo, u.step_hi, atomics, image, probe)
 #define OBNSL_MFMA_UNIT(UI)                                                                       \
   {                                                                                               \
     const MfmaUnit u = units[UI];                                                                 \
+    /* the part of the launch the unit belongs to: part 0 is described by the kernel's own    */ \
+    /* arguments, the others (smaller subset sizes counted by the same launch) by `extra`     */ \
+    const RowDesc* __restrict__ p_rows = rows;                                                    \
+    const ColDesc* __restrict__ p_cols = cols;                                                    \
+    uint32_t* __restrict__ p_counts = counts;                                                     \
+    uint32_t p_nrows = nrows, p_ncols = ncols_total;                                              \
+    bool p_image = (flags & GEMM_IMAGE) != 0;                                                     \
+    if (RUNS && u.part != 0) {                                                                    \
+      const GemmPart& e = extra.p[u.part - 1];                                                    \
+      p_rows = e.rows;                                                                            \
+      p_cols = e.cols;                                                                            \
+      p_counts = e.counts;                                                                        \
+      p_nrows = e.nrows;                                                                          \
+      p_ncols = e.ncols_total;                                                                    \
+      p_image = e.image != 0;                                                                     \
+    }                                                                                             \
     const uint32_t row0 = u.row_tile * TB, col0 = u.col_tile * TB;                                \
     const uint32_t jm = (flags & GEMM_ALL_BLOCKS) ? JFULL : u.blocks;                             \
     const bool atomics = (flags & GEMM_ATOMIC) != 0;                                              \
-    /* image mode: `counts` is the launch's array of tile images */                               \
-    uint32_t* image = (flags & GEMM_IMAGE) ? counts + (size_t)u.tile * (TB * TB) : nullptr;       \
+    /* image mode: the part's `counts` is its array of tile images */                             \
+    uint32_t* image = p_image ? p_counts + (size_t)u.tile * (TB * TB) : nullptr;                  \
     switch (jm) { /* uniform over the workgroup */                                                \
       case 1: OBNSL_MFMA_BODY(1, 1); break;                                                       \
       case 2: OBNSL_MFMA_BODY(1, 2); break;                                                       \
@@ -585,11 +601,11 @@ void launch_form(hipStream_t s, const GemmOperands& op, const MfmaLaunch& l, uin
 #ifdef OBNSL_PROBES
   hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC, TB, RUNS>), dim3(l.nworkgroups), dim3(2 * TB), 0, s, op.planes,
                      op.wp, op.rows, op.nrows, op.cols, op.ncols_total, l.units, l.unit_start, l.nruns, l.queue,
-                     counts, flags, l.trace);
+                     counts, flags, l.extra, l.trace);
 #else
   hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC, TB, RUNS>), dim3(l.nworkgroups), dim3(2 * TB), 0, s, op.planes,
                      op.wp, op.rows, op.nrows, op.cols, op.ncols_total, l.units, l.unit_start, l.nruns, l.queue,
-                     counts, flags);
+                     counts, flags, l.extra);
 #endif
 }
 template <int KR, int KC, int TB>

@@ -185,12 +185,21 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t x, float inv_r) {
 // score i = G(S) - Gprev[rank(S without v_i)]; Gprev belongs to the next smaller
 // subset size (g0 for the empty set).  scores may be null (G only).
 // (templated on the subset size so that the per-variable loops unroll exactly)
-template <int KT, int PARTS>
-__global__ __launch_bounds__(64) void score_reduced_kernel(
-    ReducedViews views, const RowGroupDesc* __restrict__ rgs, uint32_t nrgs,
-    uint64_t ntables, uint32_t tables_per_wg, const uint32_t* __restrict__ card,
-    const uint64_t* __restrict__ binom, uint32_t num_rows, int kind, double ess,
-    double* __restrict__ G, const double* __restrict__ Gprev, double g0,
+// Shared memory of a scorer workgroup besides the tables E (the caller declares it once,
+// whatever subset size the workgroup turns out to serve).
+template <int KCAP>
+struct ScorerShared {
+  SizeView sv[KFAST + 1];
+  uint32_t vars[4][KFAST], cards[4][KFAST];
+  uint64_t pat_base[4][1 << KCAP];   // first counter of the reduced table of a support pattern
+};
+
+template <int KT, int PARTS, int KCAP>
+__device__ __forceinline__ void reduced_body(
+    uint32_t block, uint32_t* __restrict__ E_all, ScorerShared<KCAP>& sh, const ReducedViews& views,
+    const RowGroupDesc* __restrict__ rgs, uint64_t ntables, uint32_t tables_per_wg,
+    const uint32_t* __restrict__ card, const uint64_t* __restrict__ binom, uint32_t num_rows, int kind,
+    double ess, double* __restrict__ G, const double* __restrict__ Gprev, double g0,
     double* __restrict__ scores, const double* __restrict__ lg_alpha, uint32_t e_stride,
     const uint32_t* __restrict__ wg_rg) {
   // The wavefront works on PARTS tables at a time (2 or 4: 32 or 16 lanes each):
@@ -199,23 +208,23 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
   // of that latency than one; four pay when the tables are small (few cells per
   // lane either way).  All parts pass the same barriers; a part without a table
   // idles through them.
+  static_assert(KT <= KCAP && PARTS <= 4, "shared arrays are sized for KCAP variables and four parts");
   constexpr uint32_t SC_PARTS = PARTS, SC_LANES = 64 / PARTS;
-  extern __shared__ __attribute__((aligned(16))) uint32_t E_all[];
-  __shared__ SizeView sv[KFAST + 1];
-  __shared__ uint32_t s_vars[SC_PARTS][KFAST], s_cards[SC_PARTS][KFAST];
-  __shared__ uint64_t pat_base_all[SC_PARTS][1 << KT];  // first counter of the reduced table of a support pattern
+  SizeView* sv = sh.sv;
+  uint32_t (*s_vars)[KFAST] = sh.vars;
+  uint32_t (*s_cards)[KFAST] = sh.cards;
   constexpr uint32_t k = KT;
   const uint32_t half = threadIdx.x / SC_LANES, lane = threadIdx.x % SC_LANES;
   uint32_t* E = E_all + (size_t)half * e_stride;
-  uint64_t* pat_base = pat_base_all[half];
+  uint64_t* pat_base = sh.pat_base[half];
 #pragma unroll
   for (int j = 0; j <= KFAST; ++j)
     if (threadIdx.x == (uint32_t)j) sv[j] = views.v[j];
-  const uint64_t t0 = (uint64_t)blockIdx.x * tables_per_wg;
+  const uint64_t t0 = (uint64_t)block * tables_per_wg;
   const uint64_t t1 = min(t0 + (uint64_t)tables_per_wg, ntables);
   // row group of the workgroup's first table (from the host: one load instead of a
   // binary search of dependent loads); every part advances from there through the groups
-  uint32_t g = wg_rg[blockIdx.x];
+  uint32_t g = wg_rg[block];
   RowGroupDesc rg = rgs[g];
   const uint32_t kc = k / 2, kr = k - kc;
   __syncthreads();
@@ -383,6 +392,168 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
   }
 }
 
+// One subset size per launch: G of its tables and, when `scores` is given, the k scores
+// of each (Gprev = the functional of the next smaller size, computed by an earlier launch).
+template <int KT, int PARTS>
+__global__ __launch_bounds__(64) void score_reduced_kernel(
+    ReducedViews views, const RowGroupDesc* __restrict__ rgs, uint32_t nrgs,
+    uint64_t ntables, uint32_t tables_per_wg, const uint32_t* __restrict__ card,
+    const uint64_t* __restrict__ binom, uint32_t num_rows, int kind, double ess,
+    double* __restrict__ G, const double* __restrict__ Gprev, double g0,
+    double* __restrict__ scores, const double* __restrict__ lg_alpha, uint32_t e_stride,
+    const uint32_t* __restrict__ wg_rg) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t E_all[];
+  __shared__ ScorerShared<KT> sh;
+  reduced_body<KT, PARTS, KT>(blockIdx.x, E_all, sh, views, rgs, ntables, tables_per_wg, card, binom, num_rows, kind,
+                              ess, G, Gprev, g0, scores, lg_alpha, e_stride, wg_rg);
+}
+
+// Every subset size 1..kmax (<= FUSED_KMAX) in one launch: the functional G of every
+// table of every size.  Workgroups [block_start[k], block_start[k + 1]) serve size k; the
+// scores follow from G in scores_best_kernel.  Workgroup 0 also resets the per-node
+// arg-max words (keys 0, ids all ones) that scores_best_kernel and best_parents_kernel
+// reduce into.
+__global__ __launch_bounds__(64) void functional_all_kernel(FunctionalAllArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t E_all[];
+  __shared__ ScorerShared<FUSED_KMAX> sh;
+  if (blockIdx.x == 0 && a.best_key != nullptr) {
+    for (uint32_t v = threadIdx.x; v < a.n; v += 64) {
+      a.best_key[v] = 0ull;
+      a.best_key[a.n + v] = ~0ull;
+    }
+  }
+  uint32_t k = 1;
+#pragma unroll
+  for (int j = 2; j <= FUSED_KMAX; ++j)
+    if ((uint32_t)j <= a.kmax && blockIdx.x >= a.size[j].block_start) k = j;
+#define OBNSL_FUNCTIONAL_CASE(KT)                                                                            \
+  case KT: {                                                                                                  \
+    const FunctionalSizeArgs& z = a.size[KT];                                                                 \
+    const uint32_t block = blockIdx.x - z.block_start;                                                        \
+    if (z.parts == 4)                                                                                         \
+      reduced_body<KT, 4, FUSED_KMAX>(block, E_all, sh, a.views, z.rgs, z.ntables, z.tables_per_wg, a.card,   \
+                                      a.binom, a.num_rows, a.kind, a.ess, z.G, nullptr, 0.0, nullptr,         \
+                                      a.lg_alpha, z.e_stride, z.wg_rg);                                       \
+    else                                                                                                      \
+      reduced_body<KT, 2, FUSED_KMAX>(block, E_all, sh, a.views, z.rgs, z.ntables, z.tables_per_wg, a.card,   \
+                                      a.binom, a.num_rows, a.kind, a.ess, z.G, nullptr, 0.0, nullptr,         \
+                                      a.lg_alpha, z.e_stride, z.wg_rg);                                       \
+  } break
+  switch (k) {   // uniform over the workgroup
+    OBNSL_FUNCTIONAL_CASE(1);
+    OBNSL_FUNCTIONAL_CASE(2);
+    OBNSL_FUNCTIONAL_CASE(3);
+    OBNSL_FUNCTIONAL_CASE(4);
+    OBNSL_FUNCTIONAL_CASE(5);
+    default: break;
+  }
+#undef OBNSL_FUNCTIONAL_CASE
+}
+
+// Largest v with C(v, j) <= rank; binom is [(n+1)][KMAX+1].
+__device__ __forceinline__ uint32_t unrank_step(const uint64_t* __restrict__ binom, uint32_t n, uint32_t j,
+                                                uint64_t rank) {
+  uint32_t lo = j - 1, hi = n - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (binom[mid * (KMAX + 1) + j] <= rank) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ uint64_t ordered_key(double x) {
+  const uint64_t b = (uint64_t)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// Scores of every size from the functionals, and the first pass of the per-node arg-max:
+// one thread per table t (colex rank) of size k,
+//   score(v_i | S \ v_i) = G_k[t] - G_{k-1}[rank(S \ v_i)]   (BIC: minus its penalty)
+// written to scores[k][t * k + i], and the largest ordered score per node kept in
+// best_key (reduced per workgroup in LDS first).  With a mask, only the tables it marks
+// are scored (the others belong to other shards: their entries stay untouched).
+__global__ __launch_bounds__(256) void scores_best_kernel(ScoresAllArgs a) {
+  __shared__ unsigned long long s_best[BEST_LDS_VARS];
+  uint32_t k = 1;
+#pragma unroll
+  for (int j = 2; j <= FUSED_KMAX; ++j)
+    if ((uint32_t)j <= a.kmax && blockIdx.x >= a.block_start[j]) k = j;
+  const double* __restrict__ Gk = nullptr;
+  const double* __restrict__ Gp = nullptr;
+  const uint8_t* __restrict__ mask = nullptr;
+  double* __restrict__ scores = nullptr;
+  uint64_t nsub = 0;
+  uint32_t first_block = 0, nblocks = 1;
+#pragma unroll
+  for (int j = 1; j <= FUSED_KMAX; ++j)
+    if ((uint32_t)j == k) {
+      Gk = a.G[j];
+      Gp = a.G[j - 1];
+      scores = a.scores[j];
+      mask = a.mask[j];
+      nsub = a.nsubsets[j];
+      first_block = a.block_start[j];
+      nblocks = a.block_start[j + 1] - a.block_start[j];
+    }
+  const bool use_lds = a.best_key != nullptr && a.n <= BEST_LDS_VARS;
+  if (use_lds) {
+    for (uint32_t v = threadIdx.x; v < a.n; v += 256) s_best[v] = 0ull;
+    __syncthreads();
+  }
+  const double half_log_n = 0.5 * log((double)a.num_rows);
+  for (uint64_t t = (uint64_t)(blockIdx.x - first_block) * 256 + threadIdx.x; t < nsub; t += (uint64_t)nblocks * 256) {
+    if (mask != nullptr && !mask[t]) continue;   // another shard's table
+    const double g = Gk[t];
+    uint32_t vars[FUSED_KMAX];
+    uint64_t rem = t;
+    uint32_t cells = 1;
+#pragma unroll
+    for (int j = FUSED_KMAX; j >= 1; --j) {
+      vars[j - 1] = 0;
+      if ((uint32_t)j > k) continue;
+      const uint32_t v = unrank_step(a.binom, a.n, (uint32_t)j, rem);
+      vars[j - 1] = v;
+      rem -= a.binom[v * (KMAX + 1) + j];
+      if (a.kind == OBNSL_SCORE_BIC) cells *= a.card[v];
+    }
+#pragma unroll
+    for (int i = 0; i < FUSED_KMAX; ++i) {
+      if ((uint32_t)i >= k) continue;
+      double gp = a.g0;
+      if (k > 1) {
+        uint64_t sub = 0;
+        uint32_t pos = 1;
+#pragma unroll
+        for (int j = 0; j < FUSED_KMAX; ++j) {
+          if ((uint32_t)j >= k || j == i) continue;
+          sub += a.binom[vars[j] * (KMAX + 1) + pos];
+          ++pos;
+        }
+        gp = Gp[sub];
+      }
+      double sc = g - gp;
+      if (a.kind == OBNSL_SCORE_BIC) {
+        const uint32_t r = a.card[vars[i]];
+        sc -= half_log_n * (double)(cells / r) * (double)(r - 1);
+      }
+      scores[t * k + i] = sc;
+      if (a.best_key != nullptr && sc > -INFINITY) {
+        const unsigned long long key = ordered_key(sc);
+        if (use_lds) atomicMax(&s_best[vars[i]], key);
+        else atomicMax(&a.best_key[vars[i]], key);
+      }
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (uint32_t v = threadIdx.x; v < a.n; v += 256) {
+      const unsigned long long x = s_best[v];
+      if (x) atomicMax(&a.best_key[v], x);
+    }
+  }
+}
+
 template <int KT>
 void launch_reduced_k(hipStream_t s, uint32_t parts, uint32_t grid, const ReducedScorerArgs& a) {
   if (parts == 4)
@@ -413,6 +584,14 @@ void launch_score_tables(hipStream_t s, const uint32_t* counts, const TableDesc*
 void launch_score_one(hipStream_t s, const uint32_t* counts, const TableDesc& td, int kind, double ess,
                       double* scores) {
   hipLaunchKernelGGL(score_one_kernel, dim3(1), dim3(64), 0, s, counts, td, kind, ess, scores);
+}
+
+void launch_functional_all(hipStream_t s, uint32_t grid, size_t lds_bytes, const FunctionalAllArgs& a) {
+  hipLaunchKernelGGL(functional_all_kernel, dim3(grid), dim3(64), lds_bytes, s, a);
+}
+
+void launch_scores_best(hipStream_t s, const ScoresAllArgs& a) {
+  hipLaunchKernelGGL(scores_best_kernel, dim3(a.block_start[a.kmax + 1]), dim3(256), 0, s, a);
 }
 
 void launch_score_reduced(hipStream_t s, uint32_t k, uint32_t parts, uint32_t grid, const ReducedScorerArgs& a) {

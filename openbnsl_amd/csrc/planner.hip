@@ -325,7 +325,13 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     HIP_TRY(b->items.upload(items));
     HIP_TRY(b->rgs.upload(rgs));
     b->h_tbl_start.resize(rgs.size());
-    for (size_t i = 0; i < rgs.size(); ++i) b->h_tbl_start[i] = rgs[i].tbl_start;
+    b->h_rank_part.resize(rgs.size());
+    b->h_ncolgroups.resize(rgs.size());
+    for (size_t i = 0; i < rgs.size(); ++i) {
+      b->h_tbl_start[i] = rgs[i].tbl_start;
+      b->h_rank_part[i] = rgs[i].rank_part;
+      b->h_ncolgroups[i] = rgs[i].ncolgroups;
+    }
     plan->total_items += b->nitems;
     plan->batches.push_back(std::move(b));
   }
@@ -365,36 +371,56 @@ obnsl_status resolve_events(obnsl_data* d) {
 // instructions (measured 31 / 24 / 20 ns per instruction for 1 / 2 / 4 blocks).
 static uint32_t unit_weight(uint32_t blk) { return 2 * blk + 1; }
 
-// Host-side check of a unit list before it is uploaded: every unit inside its
-// tile list, its rows, its steps and its image; every tile's steps covered exactly
-// once; the workgroup runs a partition of the list.  A list that fails is a bug in
-// this file; it is refused here rather than launched.
-static obnsl_status check_units(const Batch* b, const Plan* plan, const std::vector<MfmaUnit>& units,
+// One tile of a launch's work: which part (subset size) it belongs to and where it is.
+struct TileRef {
+  uint32_t part, tile, row_tile, col_tile, blocks;
+};
+struct PartShape {   // what check_units needs to know of a part
+  const Batch* b;
+  uint32_t tile_edge, ncols_total;
+};
+
+static void tiles_of(const Batch* b, uint32_t part, std::vector<TileRef>& out) {
+  for (size_t i = 0; i < b->h_items.size(); ++i)
+    out.push_back({part, (uint32_t)i, b->h_items[i].x, b->h_items[i].y, b->h_item_blocks[i]});
+}
+
+// Host-side check of a unit list before it is uploaded: every unit inside its part's
+// tile list, rows, columns and steps; every tile's steps covered exactly once; the
+// workgroup runs a partition of the list.  A list that fails is a bug in this file;
+// it is refused here rather than launched.
+static obnsl_status check_units(const std::vector<PartShape>& parts, const std::vector<MfmaUnit>& units,
                                 const std::vector<uint32_t>& unit_start, uint32_t steps_total) {
-  const uint32_t tb = plan->tile;
-  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> per_tile(b->h_items.size());
+  std::vector<std::vector<std::vector<std::pair<uint32_t, uint32_t>>>> per(parts.size());
+  for (size_t p = 0; p < parts.size(); ++p) per[p].resize(parts[p].b->h_items.size());
   for (const MfmaUnit& u : units) {
+    if (u.part >= parts.size()) return fail(OBNSL_ERR_RUNTIME, "internal: work unit outside the launch's parts");
+    const Batch* b = parts[u.part].b;
+    const uint32_t tb = parts[u.part].tile_edge;
     if (u.tile >= b->h_items.size()) return fail(OBNSL_ERR_RUNTIME, "internal: work unit outside the tile list");
     const uint2 it = b->h_items[u.tile];
     if (u.row_tile != it.x || u.col_tile != it.y)
       return fail(OBNSL_ERR_RUNTIME, "internal: work unit does not match its tile");
-    if ((uint64_t)u.row_tile * tb >= b->nrows || (uint64_t)u.col_tile * tb >= plan->ncols_total)
+    if ((uint64_t)u.row_tile * tb >= b->nrows || (uint64_t)u.col_tile * tb >= parts[u.part].ncols_total)
       return fail(OBNSL_ERR_RUNTIME, "internal: work unit outside the rows or columns of the launch");
     if (u.blocks < 1 || u.blocks > tb / 32 || u.blocks != b->h_item_blocks[u.tile])
       return fail(OBNSL_ERR_RUNTIME, "internal: work unit with a bad column-block count");
     if (u.step_lo >= u.step_hi || u.step_hi > steps_total || u.step_hi - u.step_lo > MFMA_MAX_STEPS)
       return fail(OBNSL_ERR_RUNTIME, "internal: work unit with a bad step range");
-    per_tile[u.tile].push_back({u.step_lo, u.step_hi});
+    per[u.part][u.tile].push_back({u.step_lo, u.step_hi});
   }
-  for (auto& v : per_tile) {
-    std::sort(v.begin(), v.end());
-    uint32_t at = 0;
-    for (auto& r : v) {
-      if (r.first != at) return fail(OBNSL_ERR_RUNTIME, "internal: work units do not cover a tile's steps exactly once");
-      at = r.second;
+  for (auto& part : per)
+    for (auto& v : part) {
+      std::sort(v.begin(), v.end());
+      uint32_t at = 0;
+      for (auto& r : v) {
+        if (r.first != at)
+          return fail(OBNSL_ERR_RUNTIME, "internal: work units do not cover a tile's steps exactly once");
+        at = r.second;
+      }
+      if (at != steps_total)
+        return fail(OBNSL_ERR_RUNTIME, "internal: work units do not cover a tile's steps exactly once");
     }
-    if (at != steps_total) return fail(OBNSL_ERR_RUNTIME, "internal: work units do not cover a tile's steps exactly once");
-  }
   if (!unit_start.empty()) {
     if (unit_start.front() != 0 || unit_start.back() != units.size())
       return fail(OBNSL_ERR_RUNTIME, "internal: workgroup runs do not cover the unit list");
@@ -404,14 +430,15 @@ static obnsl_status check_units(const Batch* b, const Plan* plan, const std::vec
   return OBNSL_OK;
 }
 
-static void dump_units(const Batch* b, const std::vector<MfmaUnit>& units, uint32_t steps_total, uint32_t target,
+static void dump_units(size_t ntiles, const std::vector<MfmaUnit>& units, uint32_t steps_total, uint32_t target,
                        uint32_t nworkgroups) {
-  std::map<std::pair<uint32_t, uint32_t>, uint32_t> hist;
-  for (auto& u : units) hist[{u.blocks, u.step_hi - u.step_lo}]++;
-  std::fprintf(stderr, "units: %zu tiles, %zu units, %u workgroups, steps %u, target %u\n", b->h_items.size(),
-               units.size(), nworkgroups, steps_total, target);
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> hist;
+  for (auto& u : units) hist[{u.part, u.blocks, u.step_hi - u.step_lo}]++;
+  std::fprintf(stderr, "units: %zu tiles, %zu units, %u workgroups, steps %u, target %u\n", ntiles, units.size(),
+               nworkgroups, steps_total, target);
   for (auto& h : hist)
-    std::fprintf(stderr, "  blocks %u steps %u: %u units\n", h.first.first, h.first.second, h.second);
+    std::fprintf(stderr, "  part %u blocks %u steps %u: %u units\n", std::get<0>(h.first), std::get<1>(h.first),
+                 std::get<2>(h.first), h.second);
 }
 
 // Work units of the matrix-core launch of one batch: every tile is cut along the
@@ -435,6 +462,7 @@ static obnsl_status build_units(Batch* b, const Plan* plan, uint32_t steps_total
     if (ns > 1) split = true;
     for (uint32_t sidx = 0; sidx < ns; ++sidx) {
       MfmaUnit u;
+      std::memset(&u, 0, sizeof(u));
       u.row_tile = b->h_items[i].x;
       u.col_tile = b->h_items[i].y;
       u.step_lo = (uint32_t)((uint64_t)steps_total * sidx / ns);
@@ -450,8 +478,8 @@ static obnsl_status build_units(Batch* b, const Plan* plan, uint32_t steps_total
                    });
   units.reserve(tmp.size());
   for (auto& t : tmp) units.push_back(t.second);
-  OB_TRY(check_units(b, plan, units, {}, steps_total));
-  if (env().dump_units) dump_units(b, units, steps_total, target, (uint32_t)units.size());   // tools/mfma_rate.py
+  OB_TRY(check_units({{b, plan->tile, plan->ncols_total}}, units, {}, steps_total));
+  if (env().dump_units) dump_units(b->h_items.size(), units, steps_total, target, (uint32_t)units.size());
   HIP_TRY(b->units.upload(units));
   b->nunits = (uint32_t)units.size();
   b->nworkgroups = b->nunits;
@@ -462,21 +490,19 @@ static obnsl_status build_units(Batch* b, const Plan* plan, uint32_t steps_total
   return OBNSL_OK;
 }
 
-// The same launch as runs of units for persistent workgroups.  The contraction of the
-// whole launch is laid out as one line -- tile after tile, largest first, each step
-// weighted by its cost -- and cut in phases: the first phase into `slots` runs of equal
-// cost, one per workgroup the chip holds at once (its first run); phase p after it into
-// pieces[p] x slots shorter runs that the workgroups take from a queue as they finish,
-// so that the launch ends evenly whatever slowed some of them down.  A run that crosses
-// a tile boundary becomes one unit per tile.  `target` encodes the slots for the cache test
-// (phases and pieces are fixed per process).
-static obnsl_status build_runs(Batch* b, const Plan* plan, uint32_t steps_total, uint32_t slots,
-                               const std::vector<double>& phases, const std::vector<uint32_t>& pieces,
-                               uint32_t target) {
-  if (b->units_steps == steps_total && b->units_target == target && b->nunits) return OBNSL_OK;
-  const size_t nt = b->h_items.size();
+// The launch as runs of units.  The contraction of the whole launch is laid out as one
+// line -- tile after tile in the order given, each step weighted by its cost -- and cut in
+// phases: the first phase into `slots` runs of equal cost, one per workgroup the chip
+// holds at once; phase p after it into pieces[p] x slots shorter runs that even out the
+// end of the launch.  A run that crosses a tile boundary becomes one unit per tile.
+static void cut_runs(const std::vector<TileRef>& tiles, uint32_t steps_total, uint32_t slots,
+                     const std::vector<double>& phases, const std::vector<uint32_t>& pieces,
+                     std::vector<MfmaUnit>& units, std::vector<uint32_t>& unit_start) {
+  units.clear();
+  unit_start.clear();
+  const size_t nt = tiles.size();
   std::vector<uint64_t> start(nt + 1, 0);   // position of each tile on the line
-  for (size_t i = 0; i < nt; ++i) start[i + 1] = start[i] + (uint64_t)unit_weight(b->h_item_blocks[i]) * steps_total;
+  for (size_t i = 0; i < nt; ++i) start[i + 1] = start[i] + (uint64_t)unit_weight(tiles[i].blocks) * steps_total;
   const double total = (double)start[nt];
   // a point of the line as (tile, step), rounded to whole steps
   auto locate = [&](double x, size_t& tile, uint32_t& step) {
@@ -487,7 +513,7 @@ static obnsl_status build_runs(Batch* b, const Plan* plan, uint32_t steps_total,
     }
     size_t i = std::upper_bound(start.begin(), start.end(), (uint64_t)x) - start.begin() - 1;
     i = std::min(i, nt - 1);
-    const double w = (double)unit_weight(b->h_item_blocks[i]);
+    const double w = (double)unit_weight(tiles[i].blocks);
     uint32_t st = (uint32_t)std::min<double>(steps_total, std::floor((x - (double)start[i]) / w + 0.5));
     if (st >= steps_total) {
       ++i;
@@ -496,8 +522,6 @@ static obnsl_status build_runs(Batch* b, const Plan* plan, uint32_t steps_total,
     tile = i;
     step = st;
   };
-  std::vector<MfmaUnit> units;
-  std::vector<uint32_t> unit_start;
   size_t cur_tile = 0;
   uint32_t cur_step = 0;
   double phase_lo = 0.0;
@@ -519,12 +543,14 @@ static obnsl_status build_runs(Batch* b, const Plan* plan, uint32_t steps_total,
         const uint32_t hi = cur_tile < to_tile ? steps_total : to_step;
         const uint32_t end = std::min(hi, cur_step + MFMA_MAX_STEPS);   // f32 counts stay exact
         MfmaUnit u;
-        u.row_tile = b->h_items[cur_tile].x;
-        u.col_tile = b->h_items[cur_tile].y;
+        std::memset(&u, 0, sizeof(u));
+        u.row_tile = tiles[cur_tile].row_tile;
+        u.col_tile = tiles[cur_tile].col_tile;
         u.step_lo = cur_step;
         u.step_hi = end;
-        u.blocks = b->h_item_blocks[cur_tile];
-        u.tile = (uint32_t)cur_tile;
+        u.blocks = tiles[cur_tile].blocks;
+        u.tile = tiles[cur_tile].tile;
+        u.part = tiles[cur_tile].part;
         units.push_back(u);
         cur_step = end;
         if (cur_step == steps_total) {
@@ -536,22 +562,30 @@ static obnsl_status build_runs(Batch* b, const Plan* plan, uint32_t steps_total,
     phase_lo = phase_hi;
   }
   unit_start.push_back((uint32_t)units.size());
-  OB_TRY(check_units(b, plan, units, unit_start, steps_total));
+}
+
+// Runs of units for one batch (built once per batch and row count; `target` marks
+// the form in the cache test).  One workgroup per run, dispatched in run order as
+// workgroup slots come free.
+static obnsl_status build_runs(Batch* b, const Plan* plan, uint32_t steps_total, uint32_t slots, uint32_t target) {
+  if (b->units_steps == steps_total && b->units_target == target && b->nunits) return OBNSL_OK;
+  std::vector<TileRef> tiles;
+  tiles_of(b, 0, tiles);
+  std::vector<MfmaUnit> units;
+  std::vector<uint32_t> unit_start;
+  cut_runs(tiles, steps_total, slots, env().run_phases, env().run_pieces, units, unit_start);
+  OB_TRY(check_units({{b, plan->tile, plan->ncols_total}}, units, unit_start, steps_total));
   const uint32_t nruns = (uint32_t)unit_start.size() - 1;
-  // persistent: only the first phase's workgroups are launched and the later runs come
-  // from the queue; otherwise one workgroup per run, dispatched in run order as slots
-  // come free (which lets other launches' workgroups in between them)
-  const uint32_t nwg = env().runs_persistent ? std::min(nruns, slots) : nruns;
-  if (env().dump_units) dump_units(b, units, steps_total, target, nwg);
+  if (env().dump_units) dump_units(tiles.size(), units, steps_total, target, nruns);
   HIP_TRY(b->units.upload(units));
   HIP_TRY(b->unit_start.upload(unit_start));
   b->nunits = (uint32_t)units.size();
-  b->nworkgroups = nwg;
+  b->nworkgroups = nruns;
   b->nruns = nruns;
   b->runs = true;
   b->units_steps = steps_total;
   b->units_target = target;
-  b->units_split = units.size() > nt;
+  b->units_split = units.size() > tiles.size();
   return OBNSL_OK;
 }
 
@@ -566,93 +600,55 @@ static uint32_t want_tier(int tier) {
   return env().want[0] ? env().want[tier] : dflt[tier];
 }
 
-// One bit-GEMM launch (timed with an event pair) filling `counts` for one batch.
-obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts, bool prezeroed) {
-  if (b->nitems == 0) return OBNSL_OK;
-  if (!counts) return fail(OBNSL_ERR_RUNTIME, "internal: count launch without a table");
-  const uint32_t steps_total = d->wp / KCW;
-  // split the contraction when there are too few tiles to fill the chip
-  // (workgroups of equal length run in rounds of 2 per CU; many short ones keep
-  // the last round from idling most of the chip)
-  uint32_t ksplit = 1;
-  const uint32_t want_env = env().target_wgs;
-  // the matrix-core kernel runs two 128 x 128 workgroups per CU: a few rounds of
-  // 512 are enough, and every extra split adds the whole table in atomics
-  // (measured on the 37-variable workload, whole pass: one tile cut into ~64 units -- 16
-  // units of ~64 steps when it runs beside a launch of many tiles, whose workgroup slots
-  // it would take --, 17 tiles into ~384, more tiles into ~4096 units, at least two per
-  // tile and up to 12288 of ~96 steps (70 variables, 10^7 rows: 306 tiles, +5 % from 4096
-  // to 8192..16384 units; 37 variables, five-variable tables: 759 tiles, +4 % from 4096 to
-  // 8192) when the units add into tile images, ~896 when they add into the
-  // table with scattered atomics: short units pay their prologue and epilogue, long ones
-  // leave CUs idle at the end of the launch)
-  // split launches of 128 x 128 tiles add into tile images (up to IMAGE_MAX_BYTES of
-  // them) instead of the count table itself -- not the launches of one or two tiles:
-  // their few units' atomics cost less than the scatter launch; OBNSL_NO_IMAGE:
-  // comparison runs
-  const uint64_t img_cells = (uint64_t)b->nitems * plan->tile * plan->tile;
-  const bool image_ok = plan->mfma && !env().no_image && b->nitems > 2 &&
-                        img_cells * sizeof(uint32_t) <= env().image_max_bytes;
-  const uint32_t want = want_env ? want_env
-                        : !plan->mfma ? 8192u
-                        : b->nitems <= 2 ? (d->beside_large ? std::min(want_tier(0), std::max(16u, steps_total / 64))
-                                                            : want_tier(0))
-                        : b->nitems <= 32 ? want_tier(1)
-                        : image_ok ? std::max({want_tier(3), 2 * b->nitems,
-                                               (uint32_t)std::min<uint64_t>((uint64_t)b->nitems * steps_total / 96, 12288)})
-                                   : want_tier(2);
-  const uint32_t max_split = std::max<uint32_t>(1, steps_total / env().min_sps);
-  if (b->nitems < want) ksplit = std::min<uint32_t>((want + b->nitems - 1) / b->nitems, max_split);
-  uint32_t sps = (steps_total + ksplit - 1) / ksplit;
-  if (plan->mfma) sps = std::min(sps, MFMA_MAX_STEPS);  // f32 accumulators stay exact below 2^24
-  ksplit = (steps_total + sps - 1) / sps;
-  const uint32_t kcn = plan->kc == 0 ? 1 : plan->kc;  // kc == 0: the single ONES column
-  if (plan->mfma) {
-    if (!gemm_mfma_has(plan->kr, kcn, plan->tile)) return fail(OBNSL_ERR_RUNTIME, "internal: no bit-GEMM instance");
-    // Persistent workgroups over runs of units: short launches of 128 x 128 tiles, cut along
-    // the contraction anyway, of more than 32 tiles (fewer tiles run beside a large launch,
-    // whose workgroup slots persistent workgroups would hold).  "Short": at most 1024
-    // contraction steps per workgroup slot -- there the gap between one workgroup's end
-    // and its successor's start, ~10 us per unit, is what the form saves; longer launches
-    // are as fast with one unit per workgroup.  (Not the 3 + 2 variable form, whose
-    // persistent instance spills registers.)
-    const uint32_t slots = d->num_cus * ((plan->kr + kcn <= 5) ? 2u : 1u);
-    const uint64_t tile_steps = (uint64_t)b->nitems * steps_total;
-    const bool runs = env().runs && plan->tile == 128 && image_ok && b->nitems > 32 && b->nitems < want &&
-                      plan->kr + kcn != 5 && tile_steps >= 8ull * slots &&
-                      tile_steps <= (uint64_t)env().runs_max_steps * slots;
-    if (runs)
-      OB_TRY(build_runs(b, plan, steps_total, slots, env().run_phases, env().run_pieces, 0x80000000u | slots));
-    else
-      OB_TRY(build_units(b, plan, steps_total, std::max(want, b->nitems)));
-  }
-  int flags = ((plan->mfma ? b->units_split : ksplit > 1) ? GEMM_ATOMIC : 0) |
-              (env().no_jskip ? GEMM_ALL_BLOCKS : 0) | (env().no_2x2 ? GEMM_NO_2X2 : 0);
-  const bool image = image_ok && (flags & GEMM_ATOMIC);
-  uint32_t* table = counts;
-  if (b->runs && !(image_ok && (flags & GEMM_ATOMIC)))
-    return fail(OBNSL_ERR_RUNTIME, "internal: runs of units without tile images");
-  if (image) {
-    // (IMG_TAIL words behind the images: the run queue's counter, cleared with them)
-    HIP_TRY(b->img.ensure(img_cells + IMG_TAIL));
-    if (b->img.n < img_cells + IMG_TAIL)
-      return fail(OBNSL_ERR_RUNTIME, "internal: tile images smaller than the launch's tiles");
-    if (b->img_zeroed_epoch != d->epoch)
-      HIP_TRY(hipMemsetAsync(b->img.p, 0, (img_cells + IMG_TAIL) * sizeof(uint32_t), d->count_stream()));
-    b->img_zeroed_epoch = 0;   // about to be added into
-    b->img_wants_zero = true;
-    flags |= GEMM_IMAGE;
-    counts = b->img.p;
-    if (table == plan->red.p) plan->wants_zero = false;  // every cell is stored, none added into
-  } else {
-    if ((flags & GEMM_ATOMIC) && !prezeroed)
-      HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
-    if (counts == plan->red.p) plan->wants_zero = (flags & GEMM_ATOMIC) != 0;
-  }
-  if (d->ev_used >= 4096) {  // bound the pool: fold what has been recorded so far
-    obnsl_status st = resolve_events(d);
-    if (st != OBNSL_OK) return st;
-  }
+// How a launch over one batch is shaped: split launches of 128 x 128 tiles add into tile
+// images (up to the image budget) instead of the count table itself -- not the launches of
+// one or two tiles: their few units' atomics cost less than the scatter launch
+// (OBNSL_NO_IMAGE: comparison runs) -- and how many units it is cut into:
+// the matrix-core kernel runs two 128 x 128 workgroups per CU: a few rounds of
+// 512 are enough, and every extra split adds the whole table in atomics
+// (measured on the 37-variable workload, whole pass: one tile cut into ~64 units -- 16
+// units of ~64 steps when it runs beside a launch of many tiles, whose workgroup slots
+// it would take --, 17 tiles into ~384, more tiles into ~4096 units, at least two per
+// tile and up to 12288 of ~96 steps (70 variables, 10^7 rows: 306 tiles, +5 % from 4096
+// to 8192..16384 units; 37 variables, five-variable tables: 759 tiles, +4 % from 4096 to
+// 8192) when the units add into tile images, ~896 when they add into the
+// table with scattered atomics: short units pay their prologue and epilogue, long ones
+// leave CUs idle at the end of the launch).
+struct LaunchShape {
+  uint64_t img_cells = 0;
+  bool image_ok = false;
+  uint32_t want = 0, slots = 0, kcn = 1;
+  bool runs = false;   // short launch of many 128 x 128 tiles: runs of units per workgroup
+};
+static LaunchShape launch_shape(const obnsl_data* d, const Plan* plan, const Batch* b, uint32_t steps_total) {
+  LaunchShape sh;
+  sh.img_cells = (uint64_t)b->nitems * plan->tile * plan->tile;
+  sh.image_ok = plan->mfma && !env().no_image && b->nitems > 2 &&
+                sh.img_cells * sizeof(uint32_t) <= env().image_max_bytes;
+  sh.want = env().target_wgs ? env().target_wgs
+            : !plan->mfma ? 8192u
+            : b->nitems <= 2 ? (d->beside_large ? std::min(want_tier(0), std::max(16u, steps_total / 64))
+                                                : want_tier(0))
+            : b->nitems <= 32 ? want_tier(1)
+            : sh.image_ok ? std::max({want_tier(3), 2 * b->nitems,
+                                      (uint32_t)std::min<uint64_t>((uint64_t)b->nitems * steps_total / 96, 12288)})
+                          : want_tier(2);
+  sh.kcn = plan->kc == 0 ? 1 : plan->kc;  // kc == 0: the single ONES column
+  sh.slots = d->num_cus * ((plan->kr + sh.kcn <= 5) ? 2u : 1u);
+  // Runs of units: short launches of 128 x 128 tiles, cut along the contraction anyway, of
+  // more than 32 tiles.  "Short": at most 1024 contraction steps per workgroup slot --
+  // there the gap between one workgroup's end and its successor's start, ~10 us per
+  // unit, is what the form saves; longer launches are as fast with one unit per
+  // workgroup.  (Not the 3 + 2 variable form, whose instance with the loop spills.)
+  const uint64_t tile_steps = (uint64_t)b->nitems * steps_total;
+  sh.runs = env().runs && plan->mfma && plan->tile == 128 && sh.image_ok && b->nitems > 32 && b->nitems < sh.want &&
+            plan->kr + sh.kcn != 5 && tile_steps >= 8ull * sh.slots &&
+            tile_steps <= (uint64_t)env().runs_max_steps * sh.slots;
+  return sh;
+}
+
+static obnsl_status next_event_pair(obnsl_data* d, uint32_t k, std::pair<hipEvent_t, hipEvent_t>** out) {
+  if (d->ev_used >= 4096) OB_TRY(resolve_events(d));   // bound the pool: fold what has been recorded so far
   if (d->ev_used == d->ev.size()) {
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -660,9 +656,64 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
     d->ev.push_back({e0, e1});
     d->ev_size.push_back(0);
   }
-  d->ev_size[d->ev_used] = plan->k;
-  auto& ev = d->ev[d->ev_used++];
-  HIP_TRY(hipEventRecord(ev.first, d->count_stream()));
+  d->ev_size[d->ev_used] = k;
+  *out = &d->ev[d->ev_used++];
+  return OBNSL_OK;
+}
+
+// Tile images of a batch, cleared for the launch that is about to add into them (the
+// IMG_TAIL words behind them, the run queue's counter, with them).
+static obnsl_status prepare_images(obnsl_data* d, Plan* plan, Batch* b, uint64_t img_cells, uint32_t* table) {
+  HIP_TRY(b->img.ensure(img_cells + IMG_TAIL));
+  if (b->img.n < img_cells + IMG_TAIL)
+    return fail(OBNSL_ERR_RUNTIME, "internal: tile images smaller than the launch's tiles");
+  if (b->img_zeroed_epoch != d->epoch)
+    HIP_TRY(hipMemsetAsync(b->img.p, 0, (img_cells + IMG_TAIL) * sizeof(uint32_t), d->count_stream()));
+  b->img_zeroed_epoch = 0;   // about to be added into
+  b->img_wants_zero = true;
+  if (table == plan->red.p) plan->wants_zero = false;  // every cell is stored, none added into
+  return OBNSL_OK;
+}
+
+// One bit-GEMM launch (timed with an event pair) filling `counts` for one batch.
+obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts, bool prezeroed) {
+  if (b->nitems == 0) return OBNSL_OK;
+  if (!counts) return fail(OBNSL_ERR_RUNTIME, "internal: count launch without a table");
+  const uint32_t steps_total = d->wp / KCW;
+  const LaunchShape sh = launch_shape(d, plan, b, steps_total);
+  // split the contraction when there are too few tiles to fill the chip
+  // (workgroups of equal length run in rounds of 2 per CU; many short ones keep
+  // the last round from idling most of the chip)
+  uint32_t ksplit = 1;
+  const uint32_t max_split = std::max<uint32_t>(1, steps_total / env().min_sps);
+  if (b->nitems < sh.want) ksplit = std::min<uint32_t>((sh.want + b->nitems - 1) / b->nitems, max_split);
+  uint32_t sps = (steps_total + ksplit - 1) / ksplit;
+  if (plan->mfma) sps = std::min(sps, MFMA_MAX_STEPS);  // f32 accumulators stay exact below 2^24
+  ksplit = (steps_total + sps - 1) / sps;
+  if (plan->mfma) {
+    if (!gemm_mfma_has(plan->kr, sh.kcn, plan->tile)) return fail(OBNSL_ERR_RUNTIME, "internal: no bit-GEMM instance");
+    if (sh.runs)
+      OB_TRY(build_runs(b, plan, steps_total, sh.slots, 0x80000000u | sh.slots));
+    else
+      OB_TRY(build_units(b, plan, steps_total, std::max(sh.want, b->nitems)));
+  }
+  int flags = ((plan->mfma ? b->units_split : ksplit > 1) ? GEMM_ATOMIC : 0) |
+              (env().no_jskip ? GEMM_ALL_BLOCKS : 0) | (env().no_2x2 ? GEMM_NO_2X2 : 0);
+  const bool image = sh.image_ok && (flags & GEMM_ATOMIC);
+  if (plan->mfma && b->runs && !image) return fail(OBNSL_ERR_RUNTIME, "internal: runs of units without tile images");
+  uint32_t* table = counts;
+  if (image) {
+    OB_TRY(prepare_images(d, plan, b, sh.img_cells, table));
+    flags |= GEMM_IMAGE;
+    counts = b->img.p;
+  } else {
+    if ((flags & GEMM_ATOMIC) && !prezeroed)
+      HIP_TRY(hipMemsetAsync(counts, 0, b->ncells * sizeof(uint32_t), d->count_stream()));
+    if (counts == plan->red.p) plan->wants_zero = (flags & GEMM_ATOMIC) != 0;
+  }
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  OB_TRY(next_event_pair(d, plan->k, &ev));
+  HIP_TRY(hipEventRecord(ev->first, d->count_stream()));
   GemmOperands op;
   op.planes = d->planes.p;
   op.wp = d->wp;
@@ -671,24 +722,23 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   op.cols = plan->cols.p;
   op.ncols_total = plan->ncols_total;
   if (plan->mfma) {
-    uint64_t* trace = nullptr;
+    MfmaLaunch l;
+    std::memset(&l, 0, sizeof(l));
+    l.units = b->units.p;
+    l.unit_start = b->runs ? b->unit_start.p : nullptr;
+    l.nruns = b->runs ? b->nruns : 0;
+    l.queue = b->runs ? b->img.p + sh.img_cells : nullptr;
+    l.nworkgroups = b->nworkgroups;
 #ifdef OBNSL_PROBES
     if (d->trace_want && plan->k == d->trace_size) {
       HIP_TRY(d->trace.ensure(4 * (size_t)b->nworkgroups));
       d->trace_workgroups = b->nworkgroups;
-      trace = d->trace.p;
+      l.trace = d->trace.p;
     }
 #endif
-    MfmaLaunch l;
-    l.units = b->units.p;
-    l.unit_start = b->runs ? b->unit_start.p : nullptr;
-    l.nruns = b->runs ? b->nruns : 0;
-    l.queue = b->runs ? b->img.p + img_cells : nullptr;
-    l.nworkgroups = b->nworkgroups;
-    l.trace = trace;
-    launch_gemm_mfma(plan->kr, kcn, plan->tile, d->count_stream(), op, l, counts, flags, env().probe);
+    launch_gemm_mfma(plan->kr, sh.kcn, plan->tile, d->count_stream(), op, l, counts, flags, env().probe);
   } else {
-    launch_gemm_valu(plan->kr, kcn, plan->tile, d->count_stream(), op, b->items.p, b->nitems, b->nitems * ksplit,
+    launch_gemm_valu(plan->kr, sh.kcn, plan->tile, d->count_stream(), op, b->items.p, b->nitems, b->nitems * ksplit,
                      counts, steps_total, sps, flags);
   }
   HIP_TRY(hipGetLastError());
@@ -696,7 +746,132 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
     launch_image_scatter(plan->tile, d->count_stream(), b->img.p, b->items.p, b->nitems, b->rows.p, b->nrows, table);
     HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipEventRecord(ev.second, d->count_stream()));
+  HIP_TRY(hipEventRecord(ev->second, d->count_stream()));
+  return OBNSL_OK;
+}
+
+// Whether the counting of one pass -- the subset sizes of `parts`, largest first -- can be
+// ONE launch of persistent workgroups: a short matrix-core launch (see launch_shape)
+// whose kernel form also serves the smaller sizes (fewer variables per row and column).
+bool can_count_together(const obnsl_data* d, const std::vector<CountPart>& parts) {
+  if (!env().together || parts.empty() || parts.size() > (size_t)GEMM_MAX_PARTS) return false;
+  const uint32_t steps_total = d->wp / KCW;
+  const CountPart& top = parts[0];
+  if (!launch_shape(d, top.plan, top.b, steps_total).runs) return false;
+  for (const CountPart& p : parts)
+    if (!p.plan->mfma || p.plan->tile != 128 || p.plan->kr > top.plan->kr || p.plan->kc > top.plan->kc ||
+        p.b->nitems == 0)
+      return false;
+  return true;
+}
+
+// One launch that counts several subset sizes: parts[0] the largest (its kernel form),
+// the others smaller.  As many persistent workgroups as the chip holds take the first
+// phase of runs and then the later ones from a queue; nothing else needs to run beside
+// the launch, so no other launch competes with it for workgroup slots (two of its
+// workgroups fill a CU) and nothing waits across streams.  The largest size adds into
+// tile images, the others into their (cleared) count tables.
+obnsl_status launch_count_together(obnsl_data* d, std::vector<CountPart>& parts) {
+  if (!can_count_together(d, parts)) return fail(OBNSL_ERR_RUNTIME, "internal: launch over several sizes refused");
+  const uint32_t steps_total = d->wp / KCW;
+  const LaunchShape top_shape = launch_shape(d, parts[0].plan, parts[0].b, steps_total);
+  // the cached work list of this combination of batches
+  TogetherLaunch* tl = nullptr;
+  for (auto& c : d->together)
+    if (c->steps == steps_total && c->batches.size() == parts.size() &&
+        std::equal(parts.begin(), parts.end(), c->batches.begin(),
+                   [](const CountPart& p, const Batch* b) { return p.b == b; }))
+      tl = c.get();
+  if (!tl) {
+    auto c = std::make_unique<TogetherLaunch>();
+    c->steps = steps_total;
+    std::vector<TileRef> tiles;
+    std::vector<PartShape> shapes;
+    for (size_t p = 0; p < parts.size(); ++p) {
+      c->batches.push_back(parts[p].b);
+      tiles_of(parts[p].b, (uint32_t)p, tiles);
+      shapes.push_back({parts[p].b, parts[p].plan->tile, parts[p].plan->ncols_total});
+    }
+    // the line: tiles of every part, those with the most column blocks first
+    std::stable_sort(tiles.begin(), tiles.end(), [](const TileRef& x, const TileRef& y) { return x.blocks > y.blocks; });
+    std::vector<MfmaUnit> units;
+    std::vector<uint32_t> unit_start;
+    cut_runs(tiles, steps_total, top_shape.slots, env().together_phases, env().together_pieces, units, unit_start);
+    OB_TRY(check_units(shapes, units, unit_start, steps_total));
+    c->nruns = (uint32_t)unit_start.size() - 1;
+    c->nworkgroups = std::min(c->nruns, top_shape.slots);
+    if (env().dump_units) dump_units(tiles.size(), units, steps_total, 0, c->nworkgroups);
+    HIP_TRY(c->units.upload(units));
+    HIP_TRY(c->unit_start.upload(unit_start));
+    tl = c.get();
+    d->together.push_back(std::move(c));
+  }
+  // every part's destination: tile images (cleared) or its count table (cleared)
+  GemmOperands op;
+  std::memset(&op, 0, sizeof(op));
+  MfmaLaunch l;
+  std::memset(&l, 0, sizeof(l));
+  int flags = GEMM_ATOMIC | (env().no_jskip ? GEMM_ALL_BLOCKS : 0) | (env().no_2x2 ? GEMM_NO_2X2 : 0);
+  uint32_t* top_counts = nullptr;
+  for (size_t p = 0; p < parts.size(); ++p) {
+    CountPart& cp = parts[p];
+    const LaunchShape sh = launch_shape(d, cp.plan, cp.b, steps_total);
+    // the smaller sizes add into their tables: their few units' atomics cost less than
+    // a scatter launch each
+    cp.image = p == 0;
+    uint32_t* dst = cp.table;
+    if (cp.image) {
+      OB_TRY(prepare_images(d, cp.plan, cp.b, sh.img_cells, cp.table));
+      dst = cp.b->img.p;
+    } else {
+      if (!cp.prezeroed)
+        HIP_TRY(hipMemsetAsync(cp.table, 0, cp.b->ncells * sizeof(uint32_t), d->count_stream()));
+      if (cp.table == cp.plan->red.p) cp.plan->wants_zero = true;
+    }
+    if (p == 0) {
+      if (!cp.image) return fail(OBNSL_ERR_RUNTIME, "internal: launch over several sizes without tile images");
+      op.planes = d->planes.p;
+      op.wp = d->wp;
+      op.rows = cp.b->rows.p;
+      op.nrows = cp.b->nrows;
+      op.cols = cp.plan->cols.p;
+      op.ncols_total = cp.plan->ncols_total;
+      top_counts = dst;
+      flags |= GEMM_IMAGE;
+      l.queue = cp.b->img.p + sh.img_cells;
+    } else {
+      GemmPart& e = l.extra.p[p - 1];
+      e.rows = cp.b->rows.p;
+      e.cols = cp.plan->cols.p;
+      e.counts = dst;
+      e.nrows = cp.b->nrows;
+      e.ncols_total = cp.plan->ncols_total;
+      e.image = cp.image ? 1 : 0;
+    }
+  }
+  l.units = tl->units.p;
+  l.unit_start = tl->unit_start.p;
+  l.nruns = tl->nruns;
+  l.nworkgroups = tl->nworkgroups;
+#ifdef OBNSL_PROBES
+  if (d->trace_want && parts[0].plan->k == d->trace_size) {
+    HIP_TRY(d->trace.ensure(4 * (size_t)l.nworkgroups));
+    d->trace_workgroups = l.nworkgroups;
+    l.trace = d->trace.p;
+  }
+#endif
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  OB_TRY(next_event_pair(d, parts[0].plan->k, &ev));
+  HIP_TRY(hipEventRecord(ev->first, d->count_stream()));
+  launch_gemm_mfma(parts[0].plan->kr, top_shape.kcn, 128, d->count_stream(), op, l, top_counts, flags, env().probe);
+  HIP_TRY(hipGetLastError());
+  for (CountPart& cp : parts)
+    if (cp.image) {
+      launch_image_scatter(cp.plan->tile, d->count_stream(), cp.b->img.p, cp.b->items.p, cp.b->nitems, cp.b->rows.p,
+                           cp.b->nrows, cp.table);
+      HIP_TRY(hipGetLastError());
+    }
+  HIP_TRY(hipEventRecord(ev->second, d->count_stream()));
   return OBNSL_OK;
 }
 
@@ -738,6 +913,62 @@ obnsl_status ensure_counts(obnsl_data* d, Plan* plan) {
   return OBNSL_OK;
 }
 
+// Launch shape of the reduced-mode scorer over the tables of `plan` (subset size k).
+struct ScorerShape {
+  uint32_t tpw = 0, parts = 2, grid = 0, e_stride = 0;
+};
+static obnsl_status scorer_shape(obnsl_data* d, Plan* plan, uint32_t k, uint64_t max_cells, ScorerShape* out) {
+  Batch* b = plan->batches[0].get();
+  // a few consecutive tables per wavefront amortise the descriptor loads and
+  // the dispatch; keep at least ~16 workgroups per CU for latency hiding
+  const uint32_t tpw_env = env().tables_per_wg;
+  uint32_t tpw = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(2, b->ntables / 2048));
+  if (tpw_env) tpw = tpw_env;
+  // four tables per wavefront when the tables are small (full tables of at most 256
+  // cells, 32 counted cells per table on average over the whole size), else two.  A
+  // property of the subset size alone: G of a size must come out bit for bit the same
+  // whether it is computed for its own scores, for the next size's, whole or in shards
+  // (the two forms sum a table's cells in different orders).
+  std::vector<uint32_t> sorted_card(d->card);
+  std::sort(sorted_card.rbegin(), sorted_card.rend());
+  uint64_t own_max_cells = 1, all_tables = binom_host(d->n, k);
+  for (uint32_t i = 0; i < k; ++i) own_max_cells *= sorted_card[i];
+  const uint32_t parts = (own_max_cells <= 256 && plan->size_cells <= 32 * all_tables) ? 4 : 2;
+  tpw = (tpw + parts - 1) / parts * parts;  // a wavefront takes its tables `parts` at a time
+  const uint32_t grid = (uint32_t)((b->ntables + tpw - 1) / tpw);
+  if (b->wg_rg_tpw != tpw) {   // row group of every workgroup's first table (once per plan)
+    std::vector<uint32_t> h(grid);
+    size_t g = 0;
+    for (uint32_t w = 0; w < grid; ++w) {
+      const uint64_t t0 = (uint64_t)w * tpw;
+      while (g + 1 < b->h_tbl_start.size() && b->h_tbl_start[g + 1] <= t0) ++g;
+      h[w] = (uint32_t)g;
+    }
+    HIP_TRY(b->wg_rg.upload(h));
+    b->wg_rg_tpw = tpw;
+  }
+  out->tpw = tpw;
+  out->parts = parts;
+  out->grid = grid;
+  out->e_stride = (uint32_t)((max_cells + 3) & ~3ull);
+  return OBNSL_OK;
+}
+
+// lgamma(ess / c) for c = 1..REDUCED_MAX_CELLS on the device (from the host's libm, per ess).
+static obnsl_status lg_alpha_table(obnsl_data* d, obnsl_score_kind kind, double ess, const double** out) {
+  *out = nullptr;
+  if (kind != OBNSL_SCORE_BDEU) return OBNSL_OK;
+  auto& slot = d->lg_alpha[ess];
+  if (!slot) {
+    std::vector<double> h(REDUCED_MAX_CELLS + 1, 0.0);
+    for (uint64_t c = 1; c <= REDUCED_MAX_CELLS; ++c) h[c] = std::lgamma(ess / (double)c);
+    slot = std::make_unique<DevBuf<double>>();
+    HIP_TRY(slot->upload(h));
+  }
+  *out = slot->p;
+  return OBNSL_OK;
+}
+
 // Reduced mode: expand + evaluate the functional G for every table of `plan`
 // (and the scores, when `scores` is given) -- one score_reduced_kernel launch.
 obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views, uint32_t k,
@@ -745,53 +976,17 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
                             const double* gprev, double g0, double* scores) {
   HIP_TRY(plan->G.ensure(std::max<uint64_t>(binom_host(d->n, k), 1)));
   const double* lg_alpha = nullptr;
-  if (kind == OBNSL_SCORE_BDEU) {
-    auto& slot = d->lg_alpha[ess];
-    if (!slot) {
-      std::vector<double> h(REDUCED_MAX_CELLS + 1, 0.0);
-      for (uint64_t c = 1; c <= REDUCED_MAX_CELLS; ++c) h[c] = std::lgamma(ess / (double)c);
-      slot = std::make_unique<DevBuf<double>>();
-      HIP_TRY(slot->upload(h));
-    }
-    lg_alpha = slot->p;
-  }
+  OB_TRY(lg_alpha_table(d, kind, ess, &lg_alpha));
   Batch* b = plan->batches[0].get();
   if (b->ntables) {
-    // a few consecutive tables per wavefront amortise the descriptor loads and
-    // the dispatch; keep at least ~16 workgroups per CU for latency hiding
-    const uint32_t tpw_env = env().tables_per_wg;
-    uint32_t tpw = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(2, b->ntables / 2048));
-    if (tpw_env) tpw = tpw_env;
-    // four tables per wavefront when the tables are small (full tables of at most 256
-    // cells, 32 counted cells per table on average over the whole size), else two.  A
-    // property of the subset size alone: G of a size must come out bit for bit the same
-    // whether it is computed for its own scores, for the next size's, whole or in shards
-    // (the two forms sum a table's cells in different orders).
-    std::vector<uint32_t> sorted_card(d->card);
-    std::sort(sorted_card.rbegin(), sorted_card.rend());
-    uint64_t own_max_cells = 1, all_tables = binom_host(d->n, k);
-    for (uint32_t i = 0; i < k; ++i) own_max_cells *= sorted_card[i];
-    const uint32_t parts = (own_max_cells <= 256 && plan->size_cells <= 32 * all_tables) ? 4 : 2;
-    tpw = (tpw + parts - 1) / parts * parts;  // a wavefront takes its tables `parts` at a time
-    const uint32_t grid = (uint32_t)((b->ntables + tpw - 1) / tpw);
-    const uint32_t e_stride = (uint32_t)((max_cells + 3) & ~3ull);
-    if (b->wg_rg_tpw != tpw) {   // row group of every workgroup's first table (once per plan)
-      std::vector<uint32_t> h(grid);
-      size_t g = 0;
-      for (uint32_t w = 0; w < grid; ++w) {
-        const uint64_t t0 = (uint64_t)w * tpw;
-        while (g + 1 < b->h_tbl_start.size() && b->h_tbl_start[g + 1] <= t0) ++g;
-        h[w] = (uint32_t)g;
-      }
-      HIP_TRY(b->wg_rg.upload(h));
-      b->wg_rg_tpw = tpw;
-    }
+    ScorerShape sh;
+    OB_TRY(scorer_shape(d, plan, k, max_cells, &sh));
     ReducedScorerArgs sa;
     sa.views = views;
     sa.rgs = b->rgs.p;
     sa.nrgs = b->nrgs;
     sa.ntables = b->ntables;
-    sa.tables_per_wg = tpw;
+    sa.tables_per_wg = sh.tpw;
     sa.card = d->d_card.p;
     sa.binom = d->d_binom.p;
     sa.num_rows = (uint32_t)d->N;
@@ -802,10 +997,10 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
     sa.g0 = g0;
     sa.scores = scores;
     sa.lg_alpha = lg_alpha;
-    sa.e_stride = e_stride;
+    sa.e_stride = sh.e_stride;
     sa.wg_rg = b->wg_rg.p;
     sa.best_key = nullptr;
-    launch_score_reduced(d->stream, k, parts, grid, sa);
+    launch_score_reduced(d->stream, k, sh.parts, sh.grid, sa);
     HIP_TRY(hipGetLastError());
   }
   plan->g_epoch = d->epoch;
@@ -1125,7 +1320,8 @@ obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_
   // on the main stream by the obnsl_score_all calls that follow -- run while the
   // top size is still being counted.  The main stream joins a lane where one of
   // its count tables is first used (ensure_counts) or before the planes change
-  // (run_pack).
+  // (run_pack).  A short pass -- where those launches would compete for the chip's
+  // workgroup slots -- counts every size in ONE launch on the main stream instead.
   st = join_side(d);
   if (st != OBNSL_OK) return st;
   Plan* top = nullptr;
@@ -1134,6 +1330,68 @@ obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_
   if (top_is_requested && num_shards > 1 && top->total_items > whole_below(top)) {
     st = build_plan(d, kmax, shard, num_shards, true, &top);
     if (st != OBNSL_OK) return st;
+  }
+  {
+    // every size that still has to be counted for these row bitmaps, largest first
+    std::vector<CountPart> parts;
+    Plan* sliced_whole = nullptr;
+    bool ok = top->counted_epoch != d->epoch && !top->batches.empty();
+    auto own_table = [&](Plan* p) -> obnsl_status {
+      if (!p->red.p) {
+        HIP_TRY(p->red.ensure(std::max<uint64_t>(p->batches[0]->ncells, 1)));
+        p->zeroed_epoch = 0;  // fresh memory: not cleared by any pack
+      }
+      return OBNSL_OK;
+    };
+    if (ok) {
+      OB_TRY(own_table(top));
+      parts.push_back({top, top->batches[0].get(), top->red.p, top->zeroed_epoch == d->epoch});
+    }
+    for (uint32_t j = kmax - 1; ok && j >= 1; --j) {
+      Plan* full = nullptr;
+      OB_TRY(build_plan(d, j, 0, 1, true, &full));
+      if (full->counted_epoch == d->epoch) continue;
+      if (j == kmax - 1 && shard_lower && top_is_requested && num_shards > 1 && full->total_items >= num_shards) {
+        // this rank's slice only, written at its place in the whole table; the
+        // rest stays zero and the caller sums the tables of all ranks
+        Plan* part = nullptr;
+        OB_TRY(build_plan(d, j, shard, num_shards, true, &part));
+        const Batch* wb = full->batches[0].get();
+        Batch* pb = part->batches[0].get();
+        if (part->slice_off + pb->ncells > wb->ncells)
+          return fail(OBNSL_ERR_RUNTIME, "internal: slice outside the count table");
+        if (pb->nitems == 0) {
+          ok = false;   // (an empty slice: the separate launches handle it)
+          break;
+        }
+        OB_TRY(own_table(full));
+        sliced_whole = full;
+        parts.push_back({part, pb, full->red.p + part->slice_off, false});
+      } else {
+        OB_TRY(own_table(full));
+        parts.push_back({full, full->batches[0].get(), full->red.p, full->zeroed_epoch == d->epoch});
+      }
+    }
+    if (ok && can_count_together(d, parts)) {
+      if (sliced_whole) {
+        // the whole table must be clear around the slice
+        Batch* wb = sliced_whole->batches[0].get();
+        if (sliced_whole->zeroed_epoch != d->epoch)
+          HIP_TRY(hipMemsetAsync(sliced_whole->red.p, 0, wb->ncells * sizeof(uint32_t), d->stream));
+        sliced_whole->wants_zero = true;
+        for (CountPart& p : parts)
+          if (p.table != p.plan->red.p) p.prezeroed = true;
+      }
+      OB_TRY(launch_count_together(d, parts));
+      for (CountPart& p : parts) p.plan->counted_epoch = d->epoch;
+      if (sliced_whole) {
+        sliced_whole->counted_epoch = d->epoch;
+        sliced_whole->awaits_sum = true;
+        if (sum_size_out) *sum_size_out = kmax - 1;
+        if (sum_cells_out) *sum_cells_out = sliced_whole->batches[0]->ncells;
+      }
+      return OBNSL_OK;
+    }
   }
   // fork: the lanes start after everything queued so far (the pack)
   HIP_TRY(hipEventRecord(d->side_fork, d->stream));
@@ -1217,6 +1475,195 @@ obnsl_status whole_table(obnsl_data* d, uint32_t k, Plan** out) {
   if (it == d->plans.end() || it->second->counted_epoch != d->epoch)
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "no count table of this subset size for the current row bitmaps");
   *out = it->second.get();
+  return OBNSL_OK;
+}
+
+// Per-node best parent sets from device score tables: reset of the arg-max words and the
+// pass that finds each node's largest score (both skipped when the fused scorer has done
+// them), then the pass that picks the smallest (size, rank) among the entries that reach it.
+// `keys`: 2 n words of device memory, keys [0, n), ids [n, 2 n); null = the data set's own
+// buffer (allocated on first use).
+obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_scores, uint32_t max_parents,
+                                unsigned long long* keys, bool skip_first_pass) {
+  if (max_parents + 1 > (uint32_t)KMAX || max_parents + 1 > d->n)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
+  OB_TRY(set_device(d->device));
+  if (!keys) {
+    HIP_TRY(d->best_key.ensure(2 * (size_t)d->n));
+    keys = d->best_key.p;
+  }
+  unsigned long long* key = keys;
+  unsigned long long* id = keys + d->n;
+  if (!skip_first_pass) launch_best_init(d->stream, key, id, d->n);
+  BestArgs args;
+  std::memset(&args, 0, sizeof(args));
+  args.kmax = max_parents + 1;
+  for (uint32_t k = 1; k <= max_parents + 1; ++k) {
+    const uint64_t nsub = binom_host(d->n, k);
+    args.scores[k - 1] = d_scores[k - 1];
+    args.nsubsets[k - 1] = nsub;
+    args.block_start[k] = args.block_start[k - 1] + (uint32_t)std::min<uint64_t>((nsub + 255) / 256, 512);
+  }
+  for (int pass = skip_first_pass ? 1 : 0; pass < 2; ++pass)
+    launch_best_parents(d->stream, args, d->n, d->d_binom.p, key, id, pass);
+  HIP_TRY(hipGetLastError());
+  return OBNSL_OK;
+}
+
+// 1 per colex rank of a table the sharded plan `own` lists (built once per plan).
+static obnsl_status shard_mask(obnsl_data* d, Plan* own, uint32_t k, const uint8_t** out) {
+  if (!own->own_mask_built) {
+    std::vector<uint8_t> h(std::max<uint64_t>(binom_host(d->n, k), 1), 0);
+    for (auto& bp : own->batches) {
+      const Batch* b = bp.get();
+      for (size_t g = 0; g < b->h_rank_part.size(); ++g)
+        for (uint32_t c = 0; c < b->h_ncolgroups[g]; ++c) {
+          const uint64_t r = b->h_rank_part[g] + c;
+          if (r >= h.size()) return fail(OBNSL_ERR_RUNTIME, "internal: table rank outside its subset size");
+          h[r] = 1;
+        }
+    }
+    HIP_TRY(own->own_mask.upload(h));
+    own->own_mask_built = true;
+  }
+  *out = own->own_mask.p;
+  return OBNSL_OK;
+}
+
+// The scoring phase of exhaustive_search (src/structure_learning/exhaustive_search.cpp:47-73)
+// for every subset size 1..max_parents+1 at once, and the per-node best parent sets: one
+// launch evaluates the functional of every table of every size, one turns them into
+// scores (this shard's) and finds each node's best score, one breaks ties, one writes the
+// records.  Falls back to one obnsl_score_all per size where a size is counted per row
+// or is larger than the fused launches serve.  d_best_out may be null (scores only).
+obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, uint32_t max_parents, uint32_t shard,
+                             uint32_t num_shards, double* const* d_tables, double* d_best_out,
+                             unsigned long long* keys) {
+  if (!d || !d_tables) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  const uint32_t kmax = max_parents + 1;
+  if (kmax > (uint32_t)KMAX || kmax > d->n)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
+  if (num_shards == 0 || shard >= num_shards)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "shard must be in [0, num_shards)");
+  for (uint32_t k = 1; k <= kmax; ++k)
+    if (!d_tables[k - 1]) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null score table");
+  OB_TRY(check_kind(kind));
+  OB_TRY(set_device(d->device));
+  bool fused = kmax <= (uint32_t)FUSED_KMAX && !env().no_fused;
+  uint64_t max_cells = 1;
+  for (uint32_t k = 1; k <= kmax && fused; ++k) {
+    bool red = false;
+    OB_TRY(choose_reduced(d, k, &red, k == kmax ? &max_cells : nullptr));
+    if (!red) fused = false;
+  }
+  if (!fused) {
+    for (uint32_t k = 1; k <= kmax; ++k)
+      OB_TRY(score_all_impl(d, kind, ess, k, shard, num_shards, d_tables[k - 1], 1));
+    if (d_best_out) {
+      std::vector<const double*> ptrs(d_tables, d_tables + kmax);
+      OB_TRY(queue_best_parents(d, ptrs.data(), max_parents, keys, false));
+      if (!keys) keys = d->best_key.p;
+      launch_best_decode(d->stream, keys, keys + d->n, d->n, d_best_out);
+      HIP_TRY(hipGetLastError());
+    }
+    return OBNSL_OK;
+  }
+  if (d_best_out && !keys) {
+    HIP_TRY(d->best_key.ensure(2 * (size_t)d->n));
+    keys = d->best_key.p;
+  }
+  FunctionalAllArgs fa;
+  std::memset(&fa, 0, sizeof(fa));
+  ScoresAllArgs sa;
+  std::memset(&sa, 0, sizeof(sa));
+  Plan* listed[FUSED_KMAX + 1] = {nullptr};   // whose tables size j's workgroups walk (and whose G they fill)
+  uint32_t grid = 0;
+  size_t lds = 0;
+  for (uint32_t j = 1; j <= kmax; ++j) {
+    Plan* full = nullptr;
+    OB_TRY(build_plan(d, j, 0, 1, true, &full));
+    Plan* own = full;
+    if (num_shards > 1) OB_TRY(build_plan(d, j, shard, num_shards, true, &own));
+    // the counts the scorer reads: the whole table of every size below the top one; the top
+    // size's whole table when it was counted whole (one shard, or a small size), else this
+    // shard's own
+    Plan* use = full;
+    if (j == kmax && num_shards > 1 &&
+        !(full->total_items <= whole_below(full) || full->counted_epoch == d->epoch))
+      use = own;
+    OB_TRY(ensure_counts(d, use));
+    fa.views.v[j].red = use->red.p;
+    fa.views.v[j].rowoff = use->rowoff.p;
+    fa.views.v[j].cgs = use->cgs.p;
+    fa.views.v[j].kr = use->kr;
+    fa.views.v[j].kc = use->kc;
+    // the functional of every table of the sizes below the top one (the next size's
+    // scores subtract them), of this shard's tables at the top
+    Plan* lp = j == kmax ? own : full;
+    listed[j] = lp;
+    HIP_TRY(lp->G.ensure(std::max<uint64_t>(binom_host(d->n, j), 1)));
+    uint64_t own_cells = 1;
+    bool red_j = false;
+    OB_TRY(choose_reduced(d, j, &red_j, &own_cells));
+    ScorerShape sh;
+    Batch* b = lp->batches[0].get();
+    if (b->ntables) OB_TRY(scorer_shape(d, lp, j, own_cells, &sh));
+    FunctionalSizeArgs& z = fa.size[j];
+    z.rgs = b->rgs.p;
+    z.wg_rg = b->wg_rg.p;
+    z.G = lp->G.p;
+    z.ntables = b->ntables;
+    z.tables_per_wg = std::max(sh.tpw, 1u);
+    z.parts = sh.parts;
+    z.e_stride = sh.e_stride;
+    z.block_start = grid;
+    grid += sh.grid;
+    lds = std::max(lds, (size_t)sh.parts * sh.e_stride * sizeof(uint32_t));
+    sa.G[j] = lp->G.p;
+    sa.scores[j] = d_tables[j - 1];
+    sa.nsubsets[j] = binom_host(d->n, j);
+    if (num_shards > 1) OB_TRY(shard_mask(d, own, j, &sa.mask[j]));
+  }
+  for (uint32_t j = kmax + 1; j <= (uint32_t)FUSED_KMAX; ++j) fa.size[j].block_start = grid;
+  const double* lg_alpha = nullptr;
+  OB_TRY(lg_alpha_table(d, kind, ess, &lg_alpha));
+  fa.kmax = kmax;
+  fa.card = d->d_card.p;
+  fa.binom = d->d_binom.p;
+  fa.num_rows = (uint32_t)d->N;
+  fa.kind = (int)kind;
+  fa.ess = ess;
+  fa.lg_alpha = lg_alpha;
+  fa.best_key = d_best_out ? keys : nullptr;
+  fa.n = d->n;
+  if (grid == 0) return fail(OBNSL_ERR_RUNTIME, "internal: fused scorer without tables");
+  launch_functional_all(d->stream, grid, lds, fa);
+  HIP_TRY(hipGetLastError());
+  const double N_d = (double)d->N;
+  sa.g0 = kind == OBNSL_SCORE_BDEU ? std::lgamma(N_d + ess) - std::lgamma(ess) : N_d * std::log(N_d);
+  sa.kmax = kmax;
+  sa.card = d->d_card.p;
+  sa.binom = d->d_binom.p;
+  sa.n = d->n;
+  sa.num_rows = (uint32_t)d->N;
+  sa.kind = (int)kind;
+  sa.best_key = d_best_out ? keys : nullptr;
+  sa.block_start[1] = 0;
+  for (uint32_t j = 1; j <= kmax; ++j)
+    sa.block_start[j + 1] = sa.block_start[j] + (uint32_t)std::min<uint64_t>((sa.nsubsets[j] + 255) / 256, 2048);
+  launch_scores_best(d->stream, sa);
+  HIP_TRY(hipGetLastError());
+  for (uint32_t j = 1; j <= kmax; ++j) {
+    listed[j]->g_epoch = d->epoch;
+    listed[j]->g_kind = (int)kind;
+    listed[j]->g_ess = ess;
+  }
+  if (d_best_out) {
+    std::vector<const double*> ptrs(d_tables, d_tables + kmax);
+    OB_TRY(queue_best_parents(d, ptrs.data(), max_parents, keys, true));
+    launch_best_decode(d->stream, keys, keys + d->n, d->n, d_best_out);
+    HIP_TRY(hipGetLastError());
+  }
   return OBNSL_OK;
 }
 

@@ -58,6 +58,8 @@ SIGNATURES = {
                                           _u32p, _u64p]),
     "obnsl_best_parents_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _vp]),
     "obnsl_best_parents_device_noalloc": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _vp]),
+    "obnsl_score_pass": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32, ctypes.c_uint32,
+                                        ctypes.c_uint32, ctypes.POINTER(_vp), _vp]),
     "obnsl_combine_best_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp]),
     "obnsl_exhaustive_search": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
                                                _u64p, _f64p]),
@@ -351,6 +353,13 @@ class Data:
         """best_parents_device without any device allocation (library-held scratch)."""
         arr = (_vp * len(score_ptrs))(*score_ptrs)
         _check(lib.obnsl_best_parents_device_noalloc(self._h, arr, max_parents, out_ptr))
+
+    def score_pass(self, score_ptrs, max_parents, best_ptr=None, kind=BDEU, ess=1.0, shard=0, num_shards=1):
+        """Asynchronous: every score table of subset sizes 1..max_parents+1 (score_ptrs: device
+        pointers, one per size) and, when best_ptr is given, the per-node record of
+        best_parents_device (3 * n doubles on the device)."""
+        arr = (_vp * len(score_ptrs))(*score_ptrs)
+        _check(lib.obnsl_score_pass(self._h, kind, ess, max_parents, shard, num_shards, arr, best_ptr))
 
     def combine_best_device(self, parts_ptr, world, out_ptr):
         """Asynchronous; parts_ptr: device pointer to world * 3 * n doubles (the all-gathered

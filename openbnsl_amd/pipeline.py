@@ -25,13 +25,16 @@ class _DeviceInts:
 
 class HotPath:
     def __init__(self, codes, card, max_parents, kind=engine.BDEU, ess=1.0, rank=0, world=1,
-                 device_index=0, exchange=None):
+                 device_index=0, exchange=None, fused=True):
         """exchange: run the all-gather + combine even in a world of one rank
-        (default: only when world > 1)."""
+        (default: only when world > 1).  fused: score every subset size and reduce to the
+        per-node bests with one obnsl_score_pass call (False: one obnsl_score_all per size
+        and obnsl_best_parents_device, the same results)."""
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
         self.mp, self.kind, self.ess = max_parents, kind, ess
+        self.fused = bool(fused)
         self.dev = torch.device("cuda", device_index)
         torch.cuda.set_device(self.dev)
         self.data = engine.Data(codes, card, device=device_index)
@@ -71,10 +74,14 @@ class HotPath:
                 # a world of one rank with the exchange forced on: the same export ->
                 # all-reduce -> import round trip (the sum of one table is itself)
                 self._sum_counts(self.mp, d.counts_cells(self.mp))
-        for k in range(1, self.mp + 2):
-            d.score_all_device(k, self.ptrs[k - 1], kind=self.kind, ess=self.ess,
-                               shard=self.rank, num_shards=self.world)
-        d.best_parents_device(self.ptrs, self.mp, self.best.data_ptr())
+        if self.fused:
+            d.score_pass(self.ptrs, self.mp, self.best.data_ptr(), kind=self.kind, ess=self.ess,
+                         shard=self.rank, num_shards=self.world)
+        else:
+            for k in range(1, self.mp + 2):
+                d.score_all_device(k, self.ptrs[k - 1], kind=self.kind, ess=self.ess,
+                                   shard=self.rank, num_shards=self.world)
+            d.best_parents_device(self.ptrs, self.mp, self.best.data_ptr())
         if not self.exchange:
             return self.best
         import torch.distributed as dist
