@@ -43,6 +43,24 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0
 # dense FP4 matrix-core peak: 1024 SIMDs x (32 x 32 x 64 multiply-adds per 32 cycles) x 2.4 GHz
 MFMA_FP4_PEAK_TFLOPS = 1024 * 32 * 32 * 64 * 2 / 32 * 2.4e9 / 1e12
+# what the instruction sustains when every SIMD issues nothing else (tools/mfma_probe.hip:
+# 16.5 ns per 32 x 32 x 64 FP4 instruction and SIMD; the clock gives way under that load)
+MFMA_FP4_SUSTAINED_TFLOPS = 1024 * 32 * 32 * 64 * 2 / 16.5e-9 / 1e12
+
+
+def host_cpu():
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"model": model, "os_cpu_count": os.cpu_count(),
+            "sched_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS")}
 
 
 def make_data(spec):
@@ -106,14 +124,16 @@ def cpu_baseline(codes, card, names, max_parents, budget_s=20.0, timed_table=Non
         secs = time.perf_counter() - t0
         out = {"value": sc.size / secs, "unit": "scores/s", "cores": 1, "kind": "port",
                "sample": f"{sc.shape[0]} size-{sc.shape[1]} subsets over 6 columns, all rows, oracle.c, {secs:.1f} s"}
-    # the same restatement spread over every host core the box gives us
-    threads = min(oracle.lib.oracle_max_threads(), 16)
+    # the same restatement spread over every host core this job is given: OpenMP's own
+    # default (omp_get_max_threads(), i.e. OMP_NUM_THREADS where the box sets it -- a GPU box
+    # shares its host's cores between jobs -- else every core)
+    threads = int(oracle.lib.oracle_max_threads())
     wide = sorted(rng.choice(n, size=min(n, 20), replace=False).tolist())
     sub_codes = np.ascontiguousarray(codes[wide])
     t0 = time.perf_counter()
     sc = oracle.score_all(sub_codes, card[wide], min(k, len(wide)), nthreads=threads)
     secs = time.perf_counter() - t0
-    omp = {"value": sc.size / secs, "unit": "scores/s", "cores": threads, "kind": "port",
+    omp = {"value": sc.size / secs, "unit": "scores/s", "cores": threads, "kind": "port", "host": host_cpu(),
            "sample": f"{sc.shape[0]} size-{sc.shape[1]} subsets over {len(wide)} columns, all rows, "
                      f"oracle.c with OpenMP over subsets, {secs:.1f} s"}
     return out, omp
@@ -384,21 +404,27 @@ def main():
         # with every variable in a non-reference state (the others follow by
         # inclusion-exclusion in the scorer), each FP4 multiply-add is one AND of
         # two sample bits.  Peak = dense FP4 rate of the chip.
-        try:
-            cells = data.counts_cells(k_top) * (top_scores_rank / top_scores_all)
-        except Exception:  # noqa: BLE001
-            cells = None
+        # (the launch's own figures: a short pass counts every subset size in this one launch,
+        # and a shard counts its share of the cells)
+        info = data.count_launch_info(k_top)
+        cells = float(info["cells_asked"]) or None
         flops = 2.0 * cells * N / launches_per_step if cells else None
         ach = flops / (kernel_ms * 1e-3) / 1e12 if flops else None
         roofline = {"bound": "mfma", "achieved": ach, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / MFMA_FP4_PEAK_TFLOPS if ach else None, "traffic": traffic,
                     "traffic_unit": "GB per launch", "traffic_source": traffic_src,
+                    "frac_of_sustained": ach / MFMA_FP4_SUSTAINED_TFLOPS if ach else None,
+                    "sustained_peak": MFMA_FP4_SUSTAINED_TFLOPS,
                     "kernel": f"bitgemm_mfma_kernel (subset size {k_top}, FP4 32x32x64)",
                     "kernel_ms": kernel_ms, "launches_per_step": launches_per_step,
                     "algorithmic_flops_per_launch": flops,
                     "algorithmic_cells_per_launch": cells,
+                    "subset_sizes_in_launch": info["sizes_counted"],
+                    "tiles": info["tiles"], "work_units": info["units"], "workgroups": info["workgroups"],
+                    "mfma_cells_executed_over_algorithmic": (info["cells_computed"] / cells) if cells else None,
                     "note": "2 flops per (counted cell, sample); peak = 1024 SIMDs x 65536 FP4 "
-                            "multiply-adds per 32 cycles at 2.4 GHz"}
+                            "multiply-adds per 32 cycles at 2.4 GHz; sustained_peak = the same at the "
+                            "16.5 ns per instruction a SIMD sustains with nothing else to issue"}
     else:
         roofline = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (hbm_alg / HBM_PEAK_GBS) if hbm_alg else None, "traffic": traffic,

@@ -211,8 +211,10 @@ obnsl_status obnsl_best_parents_device(obnsl_data* d, const double* const* d_sco
  * process ends).  Calls hipMalloc / hipFree never; the kernels clear the words
  * they use, with a fill kernel (no memset node).  A data set with more than
  * OBNSL_NOALLOC_MAX_VARS variables -> OBNSL_ERR_UNSUPPORTED.  Every call on one
- * GPU uses the same array: calls that overlap on one GPU (two streams, two
- * handles) race -- serialise them. */
+ * GPU uses the same array; the library orders them on the device (each call's
+ * kernels wait for the previous call's through an event that obnsl_data_create
+ * set up, whatever their streams and data sets), so calls from two streams or
+ * two handles are safe but do not overlap. */
 obnsl_status obnsl_best_parents_device_noalloc(obnsl_data* d, const double* const* d_scores,
                                                uint32_t max_parents, double* d_out);
 
@@ -281,6 +283,11 @@ obnsl_status obnsl_group_create(const uint8_t* codes, uint64_t num_rows, uint64_
 obnsl_status obnsl_group_destroy(obnsl_group* g);
 /* Either output may be null.  *uses_rccl: 1 = RCCL collectives, 0 = device copies. */
 obnsl_status obnsl_group_info(const obnsl_group* g, uint32_t* num_devices, int* uses_rccl);
+
+/* Host time (milliseconds) the last obnsl_group_* call spent queueing the ranks'
+ * launches -- every rank on a host thread of its own, all at once -- as opposed to
+ * waiting for the devices.  No counterpart in the reference. */
+obnsl_status obnsl_group_host_time(const obnsl_group* g, double* enqueue_ms);
 
 /* The hot path over the whole group: count, score every (child, parent set)
  * with at most max_parents parents (sharded), reduce to per-node best parent
@@ -362,6 +369,13 @@ uint64_t obnsl_rank(const uint32_t* var_ids, uint32_t k);
  * reset != 0 clears the totals of every subset size after reading. */
 obnsl_status obnsl_kernel_time(obnsl_data* d, uint32_t k, double* total_ms, uint32_t* launches,
                                int reset);
+
+/* Shape of the last matrix-core count launch that was timed under subset size k (no
+ * counterpart in the reference): info_out[0..5] = tiles, work units, workgroups, cells
+ * the launch computed (tile rows x the 32-column blocks that hold a valid column),
+ * cells it was asked for, and the number of subset sizes it counted (a short pass
+ * counts every size 1..k in the one launch of size k).  All zero before any launch. */
+obnsl_status obnsl_count_launch_info(obnsl_data* d, uint32_t k, uint64_t* info_out);
 
 /* Which kernel counts the tables of subset size k on this data set (no
  * counterpart in the reference, whose one loop is contingency_table.h:52-55):

@@ -494,13 +494,21 @@ obnsl_status obnsl_best_parents_device_noalloc(obnsl_data* d, const double* cons
   unsigned long long* ptr = nullptr;
   OB_TRY(noalloc_scratch(d->device, &ptr));
   if (!ptr) return fail(OBNSL_ERR_RUNTIME, "no scratch address for this device");
+  // one user of the array at a time per GPU: this call's kernels wait for the previous
+  // user's (an event per device, created at set-up) and later users wait for these
+  OB_TRY(set_device(d->device));
+  OB_TRY(noalloc_user_begin(d->device, d->stream));
   // the arg-max kernels start from best_init_kernel's fill of [0, 2 n): what an
   // earlier (possibly larger) call left in the array is never read
   obnsl_status st = queue_best_parents(d, d_scores, max_parents, ptr, false);
-  if (st != OBNSL_OK) return st;
-  launch_best_decode(d->stream, ptr, ptr + d->n, d->n, d_out);
-  HIP_TRY(hipGetLastError());
-  return OBNSL_OK;
+  if (st == OBNSL_OK) {
+    launch_best_decode(d->stream, ptr, ptr + d->n, d->n, d_out);
+    if (hipGetLastError() != hipSuccess) st = fail(OBNSL_ERR_RUNTIME, "obnsl_best_parents_device_noalloc: launch failed");
+  }
+  const std::string msg = st == OBNSL_OK ? std::string() : std::string(last_error());
+  const obnsl_status end = noalloc_user_end(d->device, d->stream);
+  if (st != OBNSL_OK) return fail(st, msg);
+  return end;
 }
 
 obnsl_status obnsl_score_pass(obnsl_data* d, obnsl_score_kind kind, double ess, uint32_t max_parents,
@@ -624,6 +632,13 @@ obnsl_status obnsl_stream_read(const void* d_src, uint64_t bytes, void* hip_stre
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "obnsl_stream_read needs a 16-byte aligned buffer of at least 16 bytes");
   launch_stream_read(reinterpret_cast<hipStream_t>(hip_stream), static_cast<const uint4*>(d_src), bytes / 16, d_sink);
   HIP_TRY(hipGetLastError());
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_count_launch_info(obnsl_data* d, uint32_t k, uint64_t* info_out) {
+  if (!d || !info_out || k == 0 || k > (uint32_t)KMAX)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "bad obnsl_count_launch_info arguments");
+  for (int i = 0; i < 6; ++i) info_out[i] = d->launch_info[k][i];
   return OBNSL_OK;
 }
 

@@ -164,6 +164,9 @@ struct obnsl_data {
   std::vector<uint32_t> ev_size;                      // subset size of each pending pair
   uint32_t ev_used = 0;                               // pending pairs
   double acc_ms[OBNSL_MAX_SUBSET + 1] = {0};          // per subset size, since the last reset
+  // shape of the last matrix-core count launch timed under each subset size: tiles, work units,
+  // workgroups, cells computed (tile rows x valid column blocks), cells asked for, subset sizes counted
+  uint64_t launch_info[OBNSL_MAX_SUBSET + 1][6] = {{0}};
   uint32_t acc_launches[OBNSL_MAX_SUBSET + 1] = {0};
 #ifdef OBNSL_PROBES
   // timing probe: per-workgroup (begin, end, hardware id, XCC id) of the launches of one subset size
@@ -284,5 +287,7 @@ void launch_dp_backtrack(hipStream_t s, uint32_t n, const double* best_gs, const
 // Device address of the per-GPU scratch array of obnsl_best_parents_device_noalloc on
 // `device` (looked up once per device, with that device current).
 obnsl_status noalloc_scratch(int device, unsigned long long** out);
+obnsl_status noalloc_user_begin(int device, hipStream_t stream);
+obnsl_status noalloc_user_end(int device, hipStream_t stream);
 
 }  // namespace obnsl_internal

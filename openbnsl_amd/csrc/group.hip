@@ -14,8 +14,11 @@
 //   exchange 2 : all-gather of the per-node records (3 doubles per node)
 //   every rank : deterministic combine (score, then fewer parents, then rank)
 //
-// The exchanges go through RCCL (ncclCommInitAll over the group's devices, one
-// communicator per rank, group calls from this one thread).  RCCL is opened at
+// Every rank has a host thread of its own (its current HIP device set once, to the
+// rank's): the launches of a phase are queued for all ranks at the same time instead
+// of device after device from the caller's thread, whose current device is never
+// touched.  The exchanges go through RCCL (ncclCommInitAll over the group's devices, one
+// communicator per rank, group calls from the caller's thread).  RCCL is opened at
 // run time (dlopen), so the library loads where it is absent and binds to the
 // copy a host program already holds (PyTorch ships its own).  RCCL refuses a
 // device that appears twice; such a group -- several ranks sharing one GPU, which
@@ -25,13 +28,18 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "engine_internal.h"
@@ -107,8 +115,67 @@ __global__ void fill_f64_kernel(double* __restrict__ dst, double v, uint64_t n) 
     dst[i] = v;
 }
 
+// A rank's host thread: runs one task at a time with the rank's device current.
+struct Worker {
+  std::thread thread;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<obnsl_status()> task;
+  bool has_task = false, done = true, stop = false;
+  obnsl_status result = OBNSL_OK;
+  std::string error;
+  double busy_ms = 0.0;   // time the last task took on the host
+
+  void start(int device) {
+    thread = std::thread([this, device] {
+      (void)hipSetDevice(device);
+      std::unique_lock<std::mutex> lock(mu);
+      for (;;) {
+        cv.wait(lock, [this] { return has_task || stop; });
+        if (stop) return;
+        has_task = false;
+        std::function<obnsl_status()> fn = std::move(task);
+        lock.unlock();
+        const auto t0 = std::chrono::steady_clock::now();
+        const obnsl_status st = fn();
+        const std::string msg = st == OBNSL_OK ? std::string() : std::string(obnsl_last_error());
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        lock.lock();
+        result = st;
+        error = msg;
+        busy_ms = ms;
+        done = true;
+        cv.notify_all();
+      }
+    });
+  }
+  void post(std::function<obnsl_status()> fn) {
+    std::lock_guard<std::mutex> lock(mu);
+    task = std::move(fn);
+    has_task = true;
+    done = false;
+    cv.notify_all();
+  }
+  obnsl_status wait(std::string* msg) {
+    std::unique_lock<std::mutex> lock(mu);
+    cv.wait(lock, [this] { return done; });
+    if (result != OBNSL_OK && msg) *msg = error;
+    return result;
+  }
+  void shutdown() {
+    if (!thread.joinable()) return;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      stop = true;
+      cv.notify_all();
+    }
+    thread.join();
+  }
+};
+
 struct Rank {
   int device = 0;
+  std::unique_ptr<Worker> worker;
   obnsl_data* data = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ready = nullptr, done = nullptr;
@@ -130,7 +197,10 @@ struct obnsl_group {
   std::vector<Rank> ranks;
   bool use_rccl = false;
   uint32_t tables_for = 0;  // score tables are allocated for subset sizes 1..tables_for
+  double enqueue_ms = 0.0;  // host time of the per-rank phases of the last call (all ranks in parallel)
   ~obnsl_group() {
+    for (Rank& r : ranks)
+      if (r.worker) r.worker->shutdown();
     for (Rank& r : ranks) {
       (void)hipSetDevice(r.device);
       if (r.stream) (void)hipStreamSynchronize(r.stream);
@@ -150,6 +220,25 @@ struct obnsl_group {
 };
 
 namespace {
+
+// Runs fn(r) on every rank's own thread, all at once; the first failure wins (its
+// message becomes the caller's last error).
+obnsl_status on_ranks(obnsl_group* g, const std::function<obnsl_status(uint32_t)>& fn) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t r = 0; r < g->ranks.size(); ++r) g->ranks[r].worker->post([&fn, r] { return fn(r); });
+  obnsl_status first = OBNSL_OK;
+  std::string first_msg;
+  for (Rank& rk : g->ranks) {
+    std::string msg;
+    const obnsl_status st = rk.worker->wait(&msg);
+    if (st != OBNSL_OK && first == OBNSL_OK) {
+      first = st;
+      first_msg = msg;
+    }
+  }
+  g->enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return first == OBNSL_OK ? OBNSL_OK : fail(first, first_msg);
+}
 
 obnsl_status nccl_check(int rc, const char* what) {
   if (rc == 0) return OBNSL_OK;
@@ -300,14 +389,15 @@ obnsl_status all_reduce_max_f64(obnsl_group* g, const std::vector<double*>& ptr,
 }
 
 // pack (optional) -> sharded counting -> exchange 1 -> sharded scoring of sizes 1..kmax
-obnsl_status score_pass(obnsl_group* g, obnsl_score_kind kind, double ess, uint32_t kmax, int repack) {
+// (and, with `best`, each rank's per-node records of its shard)
+obnsl_status score_pass(obnsl_group* g, obnsl_score_kind kind, double ess, uint32_t kmax, int repack, bool best) {
   const uint32_t W = (uint32_t)g->ranks.size();
+  g->enqueue_ms = 0.0;
   OB_TRY(ensure_tables(g, kmax));
-  uint32_t sum_size = 0;
-  uint64_t sum_cells = 0;
-  for (uint32_t r = 0; r < W; ++r) {
+  std::vector<uint32_t> sum_size(W, 0);
+  std::vector<uint64_t> sum_cells(W, 0);
+  OB_TRY(on_ranks(g, [&](uint32_t r) -> obnsl_status {
     Rank& rk = g->ranks[r];
-    HIP_TRY(hipSetDevice(rk.device));
     if (repack) OB_TRY(obnsl_data_pack(rk.data));
     // entries of the other ranks' shards stay -inf
     for (uint32_t k = 1; k <= kmax; ++k) {
@@ -315,33 +405,24 @@ obnsl_status score_pass(obnsl_group* g, obnsl_score_kind kind, double ess, uint3
                          rk.table_len[k - 1]);
       HIP_TRY(hipGetLastError());
     }
-    uint32_t sz = 0;
-    uint64_t cells = 0;
-    OB_TRY(obnsl_precount_sharded(rk.data, kmax, r, W, &sz, &cells));
-    if (r == 0) {
-      sum_size = sz;
-      sum_cells = cells;
-    } else if (sz != sum_size || cells != sum_cells) {
+    return obnsl_precount_sharded(rk.data, kmax, r, W, &sum_size[r], &sum_cells[r]);
+  }));
+  for (uint32_t r = 1; r < W; ++r)
+    if (sum_size[r] != sum_size[0] || sum_cells[r] != sum_cells[0])
       return fail(OBNSL_ERR_RUNTIME, "internal: ranks disagree on the table to sum");
-    }
-  }
-  if (sum_size) {
+  if (sum_size[0]) {
     std::vector<uint32_t*> ptr(W);
-    for (uint32_t r = 0; r < W; ++r) {
+    OB_TRY(on_ranks(g, [&](uint32_t r) -> obnsl_status {
       uint64_t cells = 0;
-      HIP_TRY(hipSetDevice(g->ranks[r].device));
-      OB_TRY(obnsl_counts_pointer(g->ranks[r].data, sum_size, &ptr[r], &cells));
-    }
-    OB_TRY(all_reduce_sum_u32(g, ptr, sum_cells));
-    for (uint32_t r = 0; r < W; ++r) OB_TRY(obnsl_counts_mark_summed(g->ranks[r].data, sum_size));
+      return obnsl_counts_pointer(g->ranks[r].data, sum_size[0], &ptr[r], &cells);
+    }));
+    OB_TRY(all_reduce_sum_u32(g, ptr, sum_cells[0]));
+    for (uint32_t r = 0; r < W; ++r) OB_TRY(obnsl_counts_mark_summed(g->ranks[r].data, sum_size[0]));
   }
-  for (uint32_t r = 0; r < W; ++r) {
+  return on_ranks(g, [&](uint32_t r) -> obnsl_status {
     Rank& rk = g->ranks[r];
-    HIP_TRY(hipSetDevice(rk.device));
-    for (uint32_t k = 1; k <= kmax; ++k)
-      OB_TRY(obnsl_score_all(rk.data, kind, ess, k, r, W, rk.tables[k - 1], 1));
-  }
-  return OBNSL_OK;
+    return obnsl_score_pass(rk.data, kind, ess, kmax - 1, r, W, rk.tables.data(), best ? rk.best : nullptr);
+  });
 }
 
 }  // namespace
@@ -364,6 +445,8 @@ obnsl_status obnsl_group_create(const uint8_t* codes, uint64_t num_rows, uint64_
   for (uint32_t r = 0; r < num_devices; ++r) {
     Rank& rk = g->ranks[r];
     rk.device = devices[r];
+    rk.worker = std::make_unique<Worker>();
+    rk.worker->start(rk.device);
     distinct.insert(devices[r]);
     OB_TRY(obnsl_data_create(codes, num_rows, col_stride, num_vars, cardinalities, devices[r], 0, &rk.data));
     HIP_TRY(hipSetDevice(rk.device));
@@ -415,6 +498,12 @@ obnsl_status obnsl_group_info(const obnsl_group* g, uint32_t* num_devices, int* 
   return OBNSL_OK;
 }
 
+obnsl_status obnsl_group_host_time(const obnsl_group* g, double* enqueue_ms) {
+  if (!g || !enqueue_ms) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  *enqueue_ms = g->enqueue_ms;
+  return OBNSL_OK;
+}
+
 obnsl_status obnsl_group_best_parents(obnsl_group* g, obnsl_score_kind kind, double ess,
                                       uint32_t max_parents, int repack, double* best_score,
                                       uint32_t* best_size, uint64_t* best_rank) {
@@ -422,21 +511,17 @@ obnsl_status obnsl_group_best_parents(obnsl_group* g, obnsl_score_kind kind, dou
   if (!g || !best_score || !best_size || !best_rank) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
   if (max_parents + 1 > g->n) return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   const uint32_t W = (uint32_t)g->ranks.size(), kmax = max_parents + 1;
-  OB_TRY(score_pass(g, kind, ess, kmax, repack));
+  OB_TRY(score_pass(g, kind, ess, kmax, repack, true));
   std::vector<double*> send(W), recv(W);
   for (uint32_t r = 0; r < W; ++r) {
-    Rank& rk = g->ranks[r];
-    HIP_TRY(hipSetDevice(rk.device));
-    OB_TRY(obnsl_best_parents_device(rk.data, rk.tables.data(), max_parents, rk.best));
-    send[r] = rk.best;
-    recv[r] = rk.gathered;
+    send[r] = g->ranks[r].best;
+    recv[r] = g->ranks[r].gathered;
   }
   OB_TRY(all_gather_f64(g, send, recv, (uint64_t)g->n * 3));
-  for (uint32_t r = 0; r < W; ++r) {
+  OB_TRY(on_ranks(g, [&](uint32_t r) -> obnsl_status {
     Rank& rk = g->ranks[r];
-    HIP_TRY(hipSetDevice(rk.device));
-    OB_TRY(obnsl_combine_best_device(rk.data, rk.gathered, W, rk.combined));
-  }
+    return obnsl_combine_best_device(rk.data, rk.gathered, W, rk.combined);
+  }));
   // every rank holds the same combined record; read rank 0's, wait for all
   std::vector<double> h((size_t)g->n * 3);
   HIP_TRY(hipSetDevice(g->ranks[0].device));
@@ -460,7 +545,7 @@ obnsl_status obnsl_group_score_tables(obnsl_group* g, obnsl_score_kind kind, dou
   if (!g || !tables_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
   if (max_parents + 1 > g->n) return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   const uint32_t W = (uint32_t)g->ranks.size(), kmax = max_parents + 1;
-  OB_TRY(score_pass(g, kind, ess, kmax, repack));
+  OB_TRY(score_pass(g, kind, ess, kmax, repack, false));
   for (uint32_t k = 1; k <= kmax; ++k) {
     std::vector<double*> ptr(W);
     for (uint32_t r = 0; r < W; ++r) ptr[r] = g->ranks[r].tables[k - 1];
@@ -488,7 +573,7 @@ obnsl_status obnsl_group_exhaustive_search(obnsl_group* g, obnsl_score_kind kind
   if (max_parents > g->n - 1) return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   if (g->n > 64) return fail(OBNSL_ERR_INVALID_ARGUMENT, "num_of_vars must be in [0, 64]");
   const uint32_t W = (uint32_t)g->ranks.size(), kmax = max_parents + 1;
-  OB_TRY(score_pass(g, kind, ess, kmax, 0));
+  OB_TRY(score_pass(g, kind, ess, kmax, 0, false));
   for (uint32_t k = 1; k <= kmax; ++k) {
     std::vector<double*> ptr(W);
     for (uint32_t r = 0; r < W; ++r) ptr[r] = g->ranks[r].tables[k - 1];

@@ -22,6 +22,8 @@ namespace {
 
 std::mutex g_scratch_mu;
 unsigned long long* g_scratch_ptr[MAX_DEVICES] = {nullptr};  // device address of `scratch`, per device
+hipEvent_t g_scratch_done[MAX_DEVICES] = {nullptr};          // recorded behind the array's last user
+std::mutex g_scratch_user_mu[MAX_DEVICES];                   // one host thread at a time queues a user
 
 // ------------------------------------------------------------------ best parents
 __device__ __forceinline__ uint64_t ordered_key(double x) {
@@ -264,9 +266,34 @@ obnsl_status noalloc_scratch(int device, unsigned long long** out) {
     if (cur != device) return fail(OBNSL_ERR_RUNTIME, "internal: scratch lookup on a device that is not current");
     unsigned long long* ptr = nullptr;
     HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    g_scratch_done[device] = ev;
     g_scratch_ptr[device] = ptr;
   }
   *out = g_scratch_ptr[device];
+  return OBNSL_OK;
+}
+
+// Users of the array on one GPU are ordered without allocating anything: a user's stream
+// first waits for the event recorded behind the previous user (whatever its stream or
+// data set), and records it again behind its own last kernel.  begin .. end is a host-side
+// critical section per device; the set-up (noalloc_scratch) must have run on the device.
+obnsl_status noalloc_user_begin(int device, hipStream_t stream) {
+  if (device < 0 || device >= MAX_DEVICES || !g_scratch_done[device])
+    return fail(OBNSL_ERR_RUNTIME, "no scratch set up for this device");
+  g_scratch_user_mu[device].lock();
+  const hipError_t e = hipStreamWaitEvent(stream, g_scratch_done[device], 0);
+  if (e != hipSuccess) {
+    g_scratch_user_mu[device].unlock();
+    return fail(OBNSL_ERR_RUNTIME, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+  }
+  return OBNSL_OK;
+}
+obnsl_status noalloc_user_end(int device, hipStream_t stream) {
+  const hipError_t e = hipEventRecord(g_scratch_done[device], stream);
+  g_scratch_user_mu[device].unlock();
+  if (e != hipSuccess) return fail(OBNSL_ERR_RUNTIME, std::string("hipEventRecord: ") + hipGetErrorString(e));
   return OBNSL_OK;
 }
 

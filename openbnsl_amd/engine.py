@@ -58,12 +58,14 @@ SIGNATURES = {
                                           _u32p, _u64p]),
     "obnsl_best_parents_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _vp]),
     "obnsl_best_parents_device_noalloc": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _vp]),
+    "obnsl_count_launch_info": (ctypes.c_int, [_vp, ctypes.c_uint32, _u64p]),
     "obnsl_score_pass": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32, ctypes.c_uint32,
                                         ctypes.c_uint32, ctypes.POINTER(_vp), _vp]),
     "obnsl_combine_best_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp]),
     "obnsl_exhaustive_search": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_uint32,
                                                _u64p, _f64p]),
     "obnsl_exhaustive_search_tables": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _u64p, _f64p]),
+    "obnsl_group_host_time": (ctypes.c_int, [_vp, _f64p]),
     "obnsl_group_create": (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _u32p,
                                           ctypes.POINTER(ctypes.c_int), ctypes.c_uint32, ctypes.POINTER(_vp)]),
     "obnsl_group_destroy": (ctypes.c_int, [_vp]),
@@ -354,6 +356,14 @@ class Data:
         arr = (_vp * len(score_ptrs))(*score_ptrs)
         _check(lib.obnsl_best_parents_device_noalloc(self._h, arr, max_parents, out_ptr))
 
+    def count_launch_info(self, k):
+        """dict: tiles, units, workgroups, cells_computed, cells_asked, sizes_counted of the last
+        matrix-core count launch timed under subset size k."""
+        out = (ctypes.c_uint64 * 6)()
+        _check(lib.obnsl_count_launch_info(self._h, k, out))
+        return dict(zip(("tiles", "units", "workgroups", "cells_computed", "cells_asked", "sizes_counted"),
+                        [int(x) for x in out]))
+
     def score_pass(self, score_ptrs, max_parents, best_ptr=None, kind=BDEU, ess=1.0, shard=0, num_shards=1):
         """Asynchronous: every score table of subset sizes 1..max_parents+1 (score_ptrs: device
         pointers, one per size) and, when best_ptr is given, the per-node record of
@@ -436,6 +446,12 @@ class Group:
             self.close()
         except Exception:
             pass
+
+    def host_time_ms(self):
+        """Host time the last call spent queueing the ranks' launches (all ranks at once)."""
+        t = ctypes.c_double(0.0)
+        _check(lib.obnsl_group_host_time(self._h, ctypes.byref(t)))
+        return t.value
 
     def info(self):
         """(number of ranks, True when the exchanges go through RCCL)."""

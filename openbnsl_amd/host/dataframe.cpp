@@ -256,12 +256,25 @@ std::vector<std::vector<uint8_t>> DataframeWrapper::data_row_major() const {
   return out;
 }
 
+// The device engine() uploads to (or has uploaded to): OPENBNSL_DEVICE, default 0.
+int DataframeWrapper::engine_device() const {
+  if (engine_) return engine_->device();
+  int device = 0;
+  if (const char* e = std::getenv("OPENBNSL_DEVICE")) {
+    char* end = nullptr;
+    const long v = std::strtol(e, &end, 10);
+    if (end == e || *end != '\0' || v < 0 || v > 1023)
+      throw std::invalid_argument("OPENBNSL_DEVICE must be a device index");
+    device = static_cast<int>(v);
+  }
+  return device;
+}
+
 EngineData& DataframeWrapper::engine() const {
   if (!engine_) {
     if (num_of_vars == 0 || num_of_datapoints == 0)
       throw std::invalid_argument("empty data set");
-    int device = 0;
-    if (const char* e = std::getenv("OPENBNSL_DEVICE")) device = std::atoi(e);
+    const int device = engine_device();
     std::vector<uint32_t> card(num_of_values.begin(), num_of_values.end());
     engine_ = std::make_shared<EngineData>(codes.data(), num_of_datapoints,
                                            static_cast<uint32_t>(num_of_vars), card.data(), device);

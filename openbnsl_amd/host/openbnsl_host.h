@@ -63,6 +63,7 @@ struct DataframeWrapper {
 
   // device copy, created on first use (throws std::runtime_error without a GPU)
   EngineData& engine() const;
+  int engine_device() const;
 
  private:
   void finish_maps();

@@ -180,15 +180,15 @@ static std::vector<int> devices_from_env() {
   std::vector<int> out;
   const char* e = std::getenv("OPENBNSL_DEVICES");
   if (!e) return out;
-  std::string cur;
-  for (const char* p = e;; ++p) {
-    if (*p == ',' || *p == '\0') {
-      if (!cur.empty()) out.push_back(std::atoi(cur.c_str()));
-      cur.clear();
-      if (*p == '\0') break;
-    } else if (*p != ' ') {
-      cur.push_back(*p);
-    }
+  const char* p = e;
+  while (*p) {
+    char* end = nullptr;
+    const long v = std::strtol(p, &end, 10);
+    while (end && *end == ' ') ++end;
+    if (end == p || v < 0 || v > 1023 || (*end != ',' && *end != '\0'))
+      throw std::invalid_argument("OPENBNSL_DEVICES must be a comma-separated list of device indices");
+    out.push_back(static_cast<int>(v));
+    p = *end == ',' ? end + 1 : end;
   }
   return out;
 }
@@ -210,7 +210,10 @@ PDAG exhaustive_search(const DataframeWrapper& df, const ScoreType& score_type,
   // allocator.  search_from_tables() below is the same program on the host.
   std::vector<uint64_t> masks(n, 0);
   if (devices.empty()) devices = devices_from_env();
-  if (devices.size() > 1) {
+  // a list of one device is honoured too: the wrapper's own engine when it lives on that
+  // device, else a group of one rank there
+  if (devices.size() == 1 && df.engine_device() == devices[0]) devices.clear();
+  if (!devices.empty()) {
     // several GPUs: the scoring phase sharded over a group (RCCL exchanges inside
     // the engine), the dynamic program on the group's first device
     std::vector<uint32_t> card(df.num_of_values.begin(), df.num_of_values.end());

@@ -50,3 +50,16 @@ def test_no_gpu_means_loud_failure():
         engine.Data(codes, [1, 1, 1])
     with pytest.raises(RuntimeError, match="no HIP device"):
         engine.local_score([3, 4], [2], 0)
+
+
+def test_shipped_library_has_no_timing_probes_and_exports_only_the_abi():
+    """The timing probes of the matrix-core kernel skip parts of it (wrong counts by
+    construction): they exist only in tools/bin/libobnsl_engine_probes.so.  The shipped
+    library contains no probe switch and exports nothing but obnsl_* symbols."""
+    import subprocess
+    from openbnsl_amd import engine
+    data = open(engine.LIB_PATH, "rb").read()
+    assert b"OBNSL_PROBE" not in data and b"obnsl_probe_" not in data
+    out = subprocess.run(["nm", "-D", "--defined-only", engine.LIB_PATH], capture_output=True, text=True, check=True)
+    names = [line.split()[-1] for line in out.stdout.splitlines() if line.strip()]
+    assert names and all(n.startswith("obnsl_") for n in names), [n for n in names if not n.startswith("obnsl_")][:5]

@@ -45,6 +45,26 @@ def test_group_best_parents_and_tables_equal_single_device(data30, world):
     g.close()
 
 
+def test_group_ranks_are_queued_from_their_own_host_threads(data30):
+    """Host time of a pass (the launches of every rank queued, not the devices' work): every
+    rank has a host thread, so eight ranks must not cost eight single-rank passes on the
+    host.  On this box the ranks share one GPU -- and the HIP runtime's per-device locks --
+    so the bound is loose; the figures are printed for the record."""
+    codes, card = data30
+    times = {}
+    for world in (1, 8):
+        g = engine.Group(codes, card, [0] * world)
+        g.best_parents(3, repack=True)
+        ts = []
+        for _ in range(5):
+            g.best_parents(3, repack=True)
+            ts.append(g.host_time_ms())
+        times[world] = float(np.median(ts))
+        g.close()
+    print(f"group host time per pass: 1 rank {times[1]:.3f} ms, 8 ranks {times[8]:.3f} ms")
+    assert times[8] <= 4.0 * times[1] + 1.0
+
+
 def test_group_search_equals_single_device_search():
     codes, card, _, _ = synth.random_bn([2, 3, 4, 2, 3, 2, 4, 3, 2, 3, 2, 4, 3, 2], 20_000, seed=14)
     d = engine.Data(codes, card)

@@ -189,3 +189,20 @@ def test_compute_fails_loudly_without_gpu():
         ob.base.ContingencyTable([0, 1], w)
     with pytest.raises(RuntimeError, match="no HIP device"):
         ob.structure_learning.exhaustive_search(w, ob.score.BDeu(1.0), 2)
+
+
+def test_device_lists_are_validated(monkeypatch):
+    """OPENBNSL_DEVICES / OPENBNSL_DEVICE with anything but device indices raise instead of
+    silently meaning device 0 (the check runs before any GPU call)."""
+    import pandas as pd
+    import openbnsllib
+    df = pd.DataFrame({"a": ["x", "y", "x", "y"], "b": ["u", "u", "v", "v"]})
+    dfw = openbnsllib.base.DataframeWrapper(df)
+    for bad in ("a,b", "1x", "0,,1", "-1"):
+        monkeypatch.setenv("OPENBNSL_DEVICES", bad)
+        with pytest.raises(ValueError, match="OPENBNSL_DEVICES"):
+            openbnsllib.structure_learning.exhaustive_search(dfw, openbnsllib.score.BDeu(1.0), 1)
+    monkeypatch.delenv("OPENBNSL_DEVICES")
+    monkeypatch.setenv("OPENBNSL_DEVICE", "zero")
+    with pytest.raises(ValueError, match="OPENBNSL_DEVICE"):
+        openbnsllib.structure_learning.exhaustive_search(dfw, openbnsllib.score.BDeu(1.0), 1)

@@ -66,3 +66,74 @@ def test_device_search_on_22_variables_equals_the_host_restatement():
     assert total == host_total
     assert graphs.is_acyclic(parents) and all(len(p) <= mp for p in parents)
     d.close()
+
+
+def _dag_score(tables, parents):
+    """Total of the local scores of a DAG from host score tables (tables[k-1]: [C(n,k), k])."""
+    from openbnsl_amd import engine
+    total = 0.0
+    for v, ps in enumerate(parents):
+        s = sorted(list(ps) + [v])
+        total += tables[len(s) - 1][engine.rank(s), s.index(v)]
+    return total
+
+
+def test_device_search_on_26_variables():
+    """26 variables: 11 GB of dynamic-programming tables on the device (the reference's own
+    n * 2^n * 16 bytes would be 28 GB of host memory).  No CPU search finishes at this
+    size in test time, so the data are built for a known answer: 13 variables of a random
+    network and 13 independent uniform binary columns, 20000 rows.  With that many rows
+    BDeu rejects every arc that touches an independent column, so the optimum is the
+    optimum over the 13 network variables -- which the oracle's search finds in a second --
+    plus the empty-parent scores of the others.  Checked: that total to 1e-9, the total
+    against the local scores of the returned graph, acyclicity and the parent bound, the
+    per-node upper bound, and Markov equivalence of the network part with the oracle's."""
+    import oracle
+    from openbnsl_amd import engine, graphs, synth
+    mp = 2
+    cards = [2, 3, 2, 4, 2, 3, 2, 2, 3, 2, 4, 2, 3]
+    codes13, card13, _, _ = synth.random_bn(cards, 20_000, seed=26)
+    rng = np.random.default_rng(2626)
+    noise = rng.integers(0, 2, size=(13, 20_000)).astype(np.uint8)
+    codes = np.ascontiguousarray(np.concatenate([codes13, noise]))
+    card = np.concatenate([card13, np.full(13, 2, dtype=np.uint32)]).astype(np.uint32)
+    d = engine.Data(codes, card)
+    parents, total = d.exhaustive_search(mp)
+    tables = [d.score_all(k) for k in range(1, mp + 2)]
+    d.close()
+    assert graphs.is_acyclic(parents) and all(len(p) <= mp for p in parents)
+    assert abs(_dag_score(tables, parents) - total) <= 1e-9 * abs(total)
+    # no DAG can beat every node's best parent set taken alone
+    n = len(card)
+    upper = 0.0
+    for v in range(n):
+        best = -np.inf
+        for k in range(1, mp + 2):
+            sets = oracle.enumerate_subsets(n, k)
+            for i in range(k):
+                m = sets[:, i] == v
+                if m.any():
+                    best = max(best, tables[k - 1][m, i].max())
+        upper += best
+    assert total <= upper + 1e-9 * abs(upper)
+    want_parents, want_total = oracle.exhaustive_search(codes13, card13, mp)
+    noise_total = float(oracle.score_all(noise, np.full(13, 2, dtype=np.uint32), 1).sum())
+    assert abs(total - (want_total + noise_total)) <= 1e-9 * abs(total)
+    assert all(parents[v] == [] for v in range(13, n))
+    assert graphs.markov_equivalent(want_parents, parents[:13])
+
+
+def test_search_sizes_the_device_cannot_hold_are_refused():
+    """31 variables: 9 * 2^31 + 12 * 31 * 2^30 bytes of tables (about 420 GB) do not fit the
+    device; 32 and more are refused outright (the reference's `1 << n` overflows from 31,
+    src/structure_learning/exhaustive_search.cpp:30).  Both are ValueErrors, raised before
+    any table is allocated."""
+    from openbnsl_amd import engine
+    rng = np.random.default_rng(31)
+    for n, pattern in ((31, "too large for the exact subset dynamic program"), (32, r"must be in \[0, 31\]")):
+        codes = rng.integers(0, 2, size=(n, 256)).astype(np.uint8)
+        codes[:, 0], codes[:, 1] = 0, 1
+        d = engine.Data(codes, np.full(n, 2, dtype=np.uint32))
+        with pytest.raises(ValueError, match=pattern):
+            d.exhaustive_search(1)
+        d.close()

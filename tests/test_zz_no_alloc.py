@@ -42,6 +42,40 @@ def test_noalloc_best_parents_matches_the_allocating_entry_point():
     assert np.array_equal(want, have)
 
 
+def test_noalloc_allocates_nothing_and_orders_calls_from_two_streams():
+    """Device memory in use is the same before and after the calls (hipMemGetInfo), and two
+    data sets calling on two streams, back to back without synchronising, both get the
+    allocating entry point's records (the calls share one array per GPU)."""
+    import torch
+    sets = []
+    for cards, rows, seed in (([2, 3, 4, 2, 3, 2, 3, 4, 2, 3, 2, 4], 4_000, 11), ([3, 2, 2, 4, 3, 2, 3, 2, 2], 2_500, 12)):
+        codes, card, _, _ = synth.random_bn(cards, rows, seed=seed)
+        d = engine.Data(codes, card)
+        st = torch.cuda.Stream()
+        d.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            tabs = [torch.empty(d.num_subsets(k) * k, dtype=torch.float64, device="cuda") for k in (1, 2, 3)]
+            want = torch.zeros((len(cards), 3), dtype=torch.float64, device="cuda")
+            have = torch.zeros((len(cards), 3), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for k, t in enumerate(tabs, start=1):
+            d.score_all_device(k, t.data_ptr())
+        ptrs = [t.data_ptr() for t in tabs]
+        d.best_parents_device(ptrs, 2, want.data_ptr())
+        d.best_parents_device_noalloc(ptrs, 2, have.data_ptr())    # warm: every lazy allocation is done
+        sets.append((d, ptrs, want, have, tabs))
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        for d, ptrs, want, have, _ in sets:            # two streams, no synchronisation between the calls
+            d.best_parents_device_noalloc(ptrs, 2, have.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+    for d, ptrs, want, have, _ in sets:
+        assert np.array_equal(want.cpu().numpy(), have.cpu().numpy())
+        d.close()
+
+
 def test_noalloc_refuses_more_variables_than_its_scratch_holds():
     n = 4097
     rng = np.random.default_rng(0)

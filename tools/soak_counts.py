@@ -79,6 +79,55 @@ for seed in range(seed0, seed0 + cases):
         if not np.array_equal(merged[k].cpu().numpy(), kept[k].reshape(-1)):
             ok = False
             print("  SHARD MISMATCH", seed, k, world, flush=True)
+    # the pass as one call pair -- obnsl_precount (every size in one launch where the pass is
+    # short) + obnsl_score_pass (the sizes share their scorer launches): whole, then in shards
+    # with the second-largest count table summed over the ranks as a multi-GPU pass does;
+    # bit-identical tables, the per-node records equal to those of the per-size calls
+    d.pack()
+    d.precount(kmax)
+    tabs = [torch.full((kept[k].size,), float("-inf"), dtype=torch.float64, device="cuda") for k in range(1, kmax + 1)]
+    ptrs = [t.data_ptr() for t in tabs]
+    best = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    d.score_pass(ptrs, kmax - 1, best.data_ptr())
+    want_best = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    d.best_parents_device(ptrs, kmax - 1, want_best.data_ptr())
+    torch.cuda.synchronize()
+    for k in kept:
+        if not np.array_equal(tabs[k - 1].cpu().numpy(), kept[k].reshape(-1)):
+            ok = False
+            print("  PASS-CALL MISMATCH", seed, k, flush=True)
+    if not np.array_equal(best.cpu().numpy(), want_best.cpu().numpy()):
+        ok = False
+        print("  PASS-CALL BEST MISMATCH", seed, flush=True)
+    ranks = [engine.Data(codes, card) for _ in range(world)]
+    sums = [dr.precount_sharded(kmax, r, world) for r, dr in enumerate(ranks)]
+    if sums[0][0]:
+        size, cells = sums[0]
+        total = torch.zeros(cells, dtype=torch.int32, device="cuda")
+        bufs = []
+        for dr in ranks:
+            b = torch.zeros(cells, dtype=torch.int32, device="cuda")
+            dr.counts_export(size, b.data_ptr())
+            torch.cuda.synchronize()
+            total += b
+        for dr in ranks:
+            dr.counts_import(size, total.data_ptr())
+    merged = {k: torch.full((kept[k].size,), float("-inf"), dtype=torch.float64, device="cuda") for k in kept}
+    for r, dr in enumerate(ranks):
+        tabs = [torch.full((kept[k].size,), float("-inf"), dtype=torch.float64, device="cuda") for k in range(1, kmax + 1)]
+        dr.score_pass([t.data_ptr() for t in tabs], kmax - 1, None, shard=r, num_shards=world)
+        torch.cuda.synchronize()
+        for k in kept:
+            fin = torch.isfinite(tabs[k - 1])
+            if bool((fin & torch.isfinite(merged[k])).any()):
+                ok = False
+                print("  PASS-CALL SHARD OVERLAP", seed, k, r, world, flush=True)
+            merged[k] = torch.where(fin, tabs[k - 1], merged[k])
+        dr.close()
+    for k in kept:
+        if not np.array_equal(merged[k].cpu().numpy(), kept[k].reshape(-1)):
+            ok = False
+            print("  PASS-CALL SHARD MISMATCH", seed, k, world, flush=True)
     bad += not ok
     print(f"seed {seed}: n={n} N={N} kmax={kmax} paths={paths} worst rel {worst:.2e} {'ok' if ok else 'FAIL'}", flush=True)
     d.close()
