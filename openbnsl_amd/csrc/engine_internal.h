@@ -35,6 +35,7 @@ struct Env {
   bool force_hist = false;        // OBNSL_FORCE_HIST: per-row histogram path for every size
   bool force_bitgemm = false;     // OBNSL_FORCE_BITGEMM: bit-plane contraction wherever it is possible
   bool no_fused = false;          // OBNSL_NO_FUSED: one scorer launch per subset size, never the fused launches
+  bool no_table_records = false;  // OBNSL_NO_TABLE_RECORDS: the fused scorer works every table out from the descriptors
   bool runs = true;               // OBNSL_NO_RUNS clears it: one work unit per workgroup, never persistent workgroups
   std::vector<double> run_phases; // OBNSL_RUN_PHASES=80,12,8: shares (percent) of a launch per phase of runs
   std::vector<uint32_t> run_pieces;  // OBNSL_RUN_PIECES=1,1,1: runs per workgroup slot in each phase

@@ -104,6 +104,11 @@ struct Plan {
   // per-table functional G[colex rank] of this plan's tables (see score_reduced_kernel)
   DevBuf<double> G;
   DevBuf<uint8_t> own_mask;     // sharded plan: 1 per colex rank of a table this shard scores
+  // the scorer's per-table records (rank, cardinalities, where each pattern's counts start) and
+  // the layouts of the count tables (sizes 1..k) they were worked out for
+  DevBuf<uint32_t> recs;
+  bool recs_ready = false;
+  const void* recs_key[2 * (KFAST + 1)] = {nullptr};
   bool own_mask_built = false;
   uint64_t g_epoch = 0;
   int g_kind = -1;

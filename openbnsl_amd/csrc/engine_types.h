@@ -140,8 +140,12 @@ struct ReducedViews {
 
 // The fused scoring launches (every subset size at once) serve sizes up to this one.
 constexpr int FUSED_KMAX = 5;
+// Words of a table's record (see the scorer): rank, cardinalities, one start per pattern.
+constexpr uint32_t table_record_words(int k) { return (uint32_t)((4 + (1 << k) - 1 + 3) & ~3); }
 struct FunctionalSizeArgs {       // one subset size of functional_all_kernel
   const RowGroupDesc* rgs;
+  uint32_t* recs;                 // per-table records (null: none)
+  int rec_mode;                   // 0: descriptors only, 1: and write the records, 2: read the records
   const uint32_t* wg_rg;          // row group of each workgroup's first table
   double* G;                      // out: functional by colex rank
   uint64_t ntables;

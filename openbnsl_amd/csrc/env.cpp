@@ -18,6 +18,7 @@
 //   OBNSL_FORCE_HIST         per-row histogram path for every subset size
 //   OBNSL_FORCE_BITGEMM      bit-plane contraction wherever it can run
 //   OBNSL_NO_FUSED           one scorer launch per subset size instead of the launches that serve every size
+//   OBNSL_NO_TABLE_RECORDS   the fused scorer works each table out from the descriptors in every pass
 //   OBNSL_NO_RUNS            one work unit per workgroup, never persistent workgroups over runs of units
 //   OBNSL_RUN_PHASES=a,b,..  shares (percent) of such a launch per phase of runs (default 80,12,8)
 //   OBNSL_RUN_PIECES=a,b,..  runs per workgroup slot in each phase (default 1,1,1)
@@ -119,6 +120,7 @@ Env read_env() {
   x.force_hist = flag("OBNSL_FORCE_HIST");
   x.force_bitgemm = flag("OBNSL_FORCE_BITGEMM");
   x.no_fused = flag("OBNSL_NO_FUSED");
+  x.no_table_records = flag("OBNSL_NO_TABLE_RECORDS");
   x.runs = !flag("OBNSL_NO_RUNS");
   x.run_phases = {0.80, 0.12, 0.08};
   x.run_pieces = {1, 1, 1};

@@ -116,19 +116,19 @@ template <int NA, int NB, class AfterRound>
 __device__ __forceinline__ void tile_mfma(const uint32_t* __restrict__ sA,
                                           const uint32_t* __restrict__ sB, uint32_t arow,
                                           uint32_t brow, uint32_t hoff, obnsl_v16f (&acc)[NA][NB],
-                                          AfterRound after_round) {
+                                          AfterRound after_round, int rp_lo = 0, int rp_hi = 2) {
   // the words of round rd + 1 are read from LDS while round rd's instructions run
   const uint32_t* pa = &sA[arow * LDS_STRIDE + hoff];
   const uint32_t* pb = &sB[brow * LDS_STRIDE + hoff];
   uint4 wa[NA], wb[NB];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE);
+  for (int i = 0; i < NA; ++i) wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + 16 * rp_lo);
 #pragma unroll
-  for (int j = 0; j < NB; ++j) wb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE);
+  for (int j = 0; j < NB; ++j) wb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE + 16 * rp_lo);
   static_assert(KCW / 8 == 4, "two iterations of two rounds");
   // two rounds per iteration: the words of a round live in (wa, wb) and (na, nb) in turn
 #pragma unroll 1
-  for (int rp = 0; rp < 2; ++rp) {
+  for (int rp = rp_lo; rp < rp_hi; ++rp) {
     uint4 na[NA], nb[NB];
     {
       const int nx = (2 * rp + 1) * 8;
@@ -181,18 +181,20 @@ __device__ __forceinline__ void mfma_blocks(const obnsl_v8i (&a)[NA], const obns
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i][j] = fp4_mfma<J>(a[i], b[j], acc[i][j]);
 }
+// (rp_lo, rp_hi): the pairs of rounds of the slab this wave contracts -- (0, 2) the whole
+// slab; a wave that shares its blocks with another takes one pair each.
 template <int NA, int NB, class AfterRound>
 __device__ __forceinline__ void tile_mfma_pipelined(const uint32_t* __restrict__ sA,
                                                     const uint32_t* __restrict__ sB, uint32_t arow,
                                                     uint32_t brow, uint32_t hoff, obnsl_v16f (&acc)[NA][NB],
-                                                    AfterRound after_round) {
+                                                    AfterRound after_round, int rp_lo = 0, int rp_hi = 2) {
   const uint32_t* pa = &sA[arow * LDS_STRIDE + hoff];
   const uint32_t* pb = &sB[brow * LDS_STRIDE + hoff];
   uint4 wa[NA], wb[NB];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE);
+  for (int i = 0; i < NA; ++i) wa[i] = *reinterpret_cast<const uint4*>(pa + 32 * i * LDS_STRIDE + 16 * rp_lo);
 #pragma unroll
-  for (int j = 0; j < NB; ++j) wb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE);
+  for (int j = 0; j < NB; ++j) wb[j] = *reinterpret_cast<const uint4*>(pb + 32 * j * LDS_STRIDE + 16 * rp_lo);
   obnsl_v8i oa[NA], ob[NB];
   build_blocks<0, NA, NB>(wa, wb, oa, ob);
   static_assert(KCW / 8 == 4, "two iterations of two rounds");
@@ -200,7 +202,7 @@ __device__ __forceinline__ void tile_mfma_pipelined(const uint32_t* __restrict__
   // two rounds per iteration: the words of a round live in (wa, wb) and (na, nb) in
   // turn, so no round ends with copying one set into the other
 #pragma unroll 1
-  for (int rp = 0; rp < 2; ++rp) {
+  for (int rp = rp_lo; rp < rp_hi; ++rp) {
     obnsl_v8i qa[NA], qb[NB];
     uint4 na[NA], nb[NB];
 #define OBNSL_PIPE(J, JN, SRCA, SRCB)                                  \
@@ -245,7 +247,13 @@ __device__ __forceinline__ void tile_mfma_pipelined(const uint32_t* __restrict__
 // Everything after the tile is known, for one value of JM (a template
 // parameter of the whole loop nest, so that the accumulators live in the
 // accumulator registers from the first step to the epilogue).
-template <int KR, int KC, int NA, int NB, int TB>
+// KS = 2 (tiles of one or two column blocks in a launch whose units add their counts): two
+// waves share the 2 x NB blocks of a 64-row half of the tile and contract one half of every
+// slab (a pair of rounds) each, so that edge tiles amortise their operand builds over
+// more instructions (5 / 7.5 vector instructions per matrix instruction for two / one
+// column blocks, against 7.5 / 10 with one row block per wave).  The waves' partial
+// counts meet in the atomics of the epilogue.
+template <int KR, int KC, int NA, int NB, int TB, int KS = 1>
 __device__ __forceinline__ void mfma_tile_body(
     uint32_t* __restrict__ smem, const uint32_t* __restrict__ planes, uint32_t wp,
     const RowDesc* __restrict__ rows, uint32_t nrows, const ColDesc* __restrict__ cols,
@@ -284,11 +292,14 @@ __device__ __forceinline__ void mfma_tile_body(
   // 32 NB (wv & 1) .. (a 64 x 64 quadrant of a 128 tile, a 64 x 128 eighth of a 256
   // tile).  Lane (lr, h) holds row / column lr of each block, samples 128 h ..
   // 128 h + 127 of each 256-sample round.
-  static_assert(NA == 1 || 2 * 32 * NB == TB, "two waves side by side cover the tile's columns");
+  static_assert(KS != 1 || NA == 1 || 2 * 32 * NB == TB, "two waves side by side cover the tile's columns");
+  static_assert(KS == 1 || (TB == 128 && KS == 2 && NA == 2 && NB <= 2),
+                "the shared form: 2 x NB blocks per wave, a half of every slab");
   const uint32_t lane = tid & 63, wv = tid >> 6;
   const uint32_t lr = lane & 31, h4 = (lane >> 5) * 4;
-  const uint32_t wrow = NA == 1 ? wv * 32 : (wv >> 1) * 64;   // first row / column of the wave's blocks
-  const uint32_t wcol = NA == 1 ? 0 : (wv & 1) * (32 * NB);
+  // first row / column of the wave's blocks
+  const uint32_t wrow = KS == 2 ? (wv & 1) * 64 : NA == 1 ? wv * 32 : (wv >> 1) * 64;
+  const uint32_t wcol = KS != 1 ? 0 : NA == 1 ? 0 : (wv & 1) * (32 * NB);
   obnsl_v16f acc[NA][NB];
 #pragma unroll
   for (int a = 0; a < NA; ++a)
@@ -347,7 +358,9 @@ __device__ __forceinline__ void mfma_tile_body(
       if (more && !OBNSL_PROBE(PROBE_NOISSUE)) issue_loads(step + 1);
       const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
       const uint32_t* sB = sA + TB * LDS_STRIDE;
-      if constexpr (NA == 2 && NB == 2) tile_mfma_pipelined<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
+      if constexpr (KS == 2 && NB == 2) tile_mfma_pipelined<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {}, (int)(wv >> 1), (int)(wv >> 1) + 1);
+      else if constexpr (KS == 2) tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {}, (int)(wv >> 1), (int)(wv >> 1) + 1);
+      else if constexpr (NA == 2 && NB == 2) tile_mfma_pipelined<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
       else tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
       if (more && !OBNSL_PROBE(PROBE_NOWRITE)) write_slab(buf ^ 1);
       __syncthreads();
@@ -501,6 +514,9 @@ __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void b
 #define OBNSL_MFMA_BODY(NA, NB)                                                                          \
   mfma_tile_body<KR, KC, NA, NB, TB>(smem, planes, wp, p_rows, p_nrows, p_cols, p_ncols, row0, col0,      \
                                      p_counts, u.step_lo, u.step_hi, atomics, image, probe)
+#define OBNSL_MFMA_BODY_SHARED(NA, NB, KS)                                                               \
+  mfma_tile_body<KR, KC, NA, NB, TB, KS>(smem, planes, wp, p_rows, p_nrows, p_cols, p_ncols, row0, col0,  \
+                                         p_counts, u.step_lo, u.step_hi, atomics, image, probe)
 #define OBNSL_MFMA_UNIT(UI)                                                                       \
   {                                                                                               \
     const MfmaUnit u = units[UI];                                                                 \
@@ -526,8 +542,14 @@ __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void b
     /* image mode: the part's `counts` is its array of tile images */                             \
     uint32_t* image = p_image ? p_counts + (size_t)u.tile * (TB * TB) : nullptr;                  \
     switch (jm) { /* uniform over the workgroup */                                                \
-      case 1: OBNSL_MFMA_BODY(1, 1); break;                                                       \
-      case 2: OBNSL_MFMA_BODY(1, 2); break;                                                       \
+      case 1:                                                                                     \
+        if constexpr (RUNS) OBNSL_MFMA_BODY_SHARED(2, 1, 2); /* (runs always add: partial counts */ \
+        else OBNSL_MFMA_BODY(1, 1);                          /*  of several waves can meet)      */ \
+        break;                                                                                    \
+      case 2:                                                                                     \
+        if constexpr (RUNS) OBNSL_MFMA_BODY_SHARED(2, 2, 2);                                      \
+        else OBNSL_MFMA_BODY(1, 2);                                                               \
+        break;                                                                                    \
       case 3: OBNSL_MFMA_BODY(1, 3); break;                                                       \
       default:                                                                                    \
         if constexpr (TB == 128) {                                                                \
@@ -564,6 +586,7 @@ __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void b
   }
 #undef OBNSL_MFMA_UNIT
 #undef OBNSL_MFMA_BODY
+#undef OBNSL_MFMA_BODY_SHARED
 #ifdef OBNSL_PROBES
   if (trace != nullptr && threadIdx.x == 0) {
     // per workgroup: begin, end (100 MHz counter), hardware id, XCC id | runs done << 8

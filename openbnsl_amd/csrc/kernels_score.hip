@@ -194,14 +194,14 @@ struct ScorerShared {
   uint64_t pat_base[4][1 << KCAP];   // first counter of the reduced table of a support pattern
 };
 
-template <int KT, int PARTS, int KCAP>
+template <int KT, int PARTS, int KCAP, bool READ_RECORDS = false>
 __device__ __forceinline__ void reduced_body(
     uint32_t block, uint32_t* __restrict__ E_all, ScorerShared<KCAP>& sh, const ReducedViews& views,
     const RowGroupDesc* __restrict__ rgs, uint64_t ntables, uint32_t tables_per_wg,
     const uint32_t* __restrict__ card, const uint64_t* __restrict__ binom, uint32_t num_rows, int kind,
     double ess, double* __restrict__ G, const double* __restrict__ Gprev, double g0,
     double* __restrict__ scores, const double* __restrict__ lg_alpha, uint32_t e_stride,
-    const uint32_t* __restrict__ wg_rg) {
+    const uint32_t* __restrict__ wg_rg, uint32_t* __restrict__ recs = nullptr, int rec_mode = 0) {
   // The wavefront works on PARTS tables at a time (2 or 4: 32 or 16 lanes each):
   // a table is a chain of dependent loads (descriptors -> table bases -> counts
   // -> G of the subsets below), and several chains in flight per wave hide more
@@ -222,10 +222,25 @@ __device__ __forceinline__ void reduced_body(
     if (threadIdx.x == (uint32_t)j) sv[j] = views.v[j];
   const uint64_t t0 = (uint64_t)block * tables_per_wg;
   const uint64_t t1 = min(t0 + (uint64_t)tables_per_wg, ntables);
+  // What a table needs before its counts can be gathered -- its rank, its variables'
+  // cardinalities and where the reduced table of each support pattern starts -- takes a
+  // chain of five dependent loads to work out from the descriptors, and is the same in
+  // every pass.  rec_mode 1 leaves it behind as a record per table (REC_WORDS words:
+  // rank, cardinalities - 1 as bytes, one start per pattern); rec_mode 2 reads that
+  // record instead of the descriptors: one load in place of the chain.
+  constexpr uint32_t REC_WORDS = table_record_words(KT);
+  constexpr bool from_records = READ_RECORDS;
   // row group of the workgroup's first table (from the host: one load instead of a
   // binary search of dependent loads); every part advances from there through the groups
-  uint32_t g = wg_rg[block];
-  RowGroupDesc rg = rgs[g];
+  uint32_t g = 0;
+  RowGroupDesc rg;
+  rg.rank_part = 0;
+  rg.tbl_start = 0;
+  rg.ncolgroups = 0;
+  if (!from_records) {
+    g = wg_rg[block];
+    rg = rgs[g];
+  }
   const uint32_t kc = k / 2, kr = k - kc;
   __syncthreads();
   const ColGroupDesc* __restrict__ own_cgs = sv[k].cgs;
@@ -242,9 +257,25 @@ __device__ __forceinline__ void reduced_body(
       cards[i] = 1;
       inv_card[i] = 1.0f;
     }
-    if (active) {
+    uint64_t rank = 0;
+    if (active && from_records) {
+      const uint32_t* __restrict__ rec = recs + t * REC_WORDS;
+      rank = (uint64_t)rec[0] | ((uint64_t)rec[1] << 32);
+      const uint32_t c_lo = rec[2], c_hi = rec[3];
+#pragma unroll
+      for (int i = 0; i < KFAST; ++i) {
+        if (i < (int)k) {
+          cards[i] = (((i < 4 ? c_lo : c_hi) >> (8 * (i & 3))) & 0xffu) + 1u;
+          inv_card[i] = 1.0f / (float)cards[i];
+          cells *= cards[i];
+        }
+      }
+      for (uint32_t pat = lane + 1; pat < (1u << k); pat += SC_LANES) pat_base[pat] = rec[3 + pat];
+    }
+    if (active && !from_records) {
       while (t >= rg.tbl_start + rg.ncolgroups) rg = rgs[++g];
       gamma = (uint32_t)(t - rg.tbl_start);
+      rank = rg.rank_part + gamma;
       // (fixed-trip loops guarded by i < k keep these small arrays in registers)
       ColGroupDesc cg;
       if (kc > 0) cg = own_cgs[gamma];
@@ -281,7 +312,23 @@ __device__ __forceinline__ void reduced_body(
           }
         }
         const uint32_t col_before = s.kc ? s.cgs[colrank].col_before : 0;
-        pat_base[pat] = s.rowoff[rowrank] + (uint64_t)col_before * mred;
+        const uint64_t start = s.rowoff[rowrank] + (uint64_t)col_before * mred;
+        pat_base[pat] = start;
+        if (rec_mode == 1) recs[t * REC_WORDS + 3 + pat] = (uint32_t)start;
+      }
+      if (rec_mode == 1 && lane == 0) {
+        uint32_t c_lo = 0, c_hi = 0;
+#pragma unroll
+        for (int i = 0; i < KFAST; ++i) {
+          if (i >= (int)k) continue;
+          if (i < 4) c_lo |= ((cards[i] - 1u) & 0xffu) << (8 * i);
+          else c_hi |= ((cards[i] - 1u) & 0xffu) << (8 * (i - 4));
+        }
+        uint32_t* rec = recs + t * REC_WORDS;
+        rec[0] = (uint32_t)rank;
+        rec[1] = (uint32_t)(rank >> 32);
+        rec[2] = c_lo;
+        rec[3] = c_hi;
       }
     }
     __syncthreads();
@@ -340,7 +387,6 @@ __device__ __forceinline__ void reduced_body(
       }
       __syncthreads();
     }
-    const uint64_t rank = rg.rank_part + gamma;
     double gsum = 0.0;
     if (active) {
       if (kind == OBNSL_SCORE_BDEU) {
@@ -413,6 +459,7 @@ __global__ __launch_bounds__(64) void score_reduced_kernel(
 // scores follow from G in scores_best_kernel.  Workgroup 0 also resets the per-node
 // arg-max words (keys 0, ids all ones) that scores_best_kernel and best_parents_kernel
 // reduce into.
+template <bool READ_RECORDS>
 __global__ __launch_bounds__(64) void functional_all_kernel(FunctionalAllArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t E_all[];
   __shared__ ScorerShared<FUSED_KMAX> sh;
@@ -431,13 +478,13 @@ __global__ __launch_bounds__(64) void functional_all_kernel(FunctionalAllArgs a)
     const FunctionalSizeArgs& z = a.size[KT];                                                                 \
     const uint32_t block = blockIdx.x - z.block_start;                                                        \
     if (z.parts == 4)                                                                                         \
-      reduced_body<KT, 4, FUSED_KMAX>(block, E_all, sh, a.views, z.rgs, z.ntables, z.tables_per_wg, a.card,   \
+      reduced_body<KT, 4, FUSED_KMAX, READ_RECORDS>(block, E_all, sh, a.views, z.rgs, z.ntables, z.tables_per_wg, a.card, \
                                       a.binom, a.num_rows, a.kind, a.ess, z.G, nullptr, 0.0, nullptr,         \
-                                      a.lg_alpha, z.e_stride, z.wg_rg);                                       \
+                                      a.lg_alpha, z.e_stride, z.wg_rg, z.recs, z.rec_mode);                   \
     else                                                                                                      \
-      reduced_body<KT, 2, FUSED_KMAX>(block, E_all, sh, a.views, z.rgs, z.ntables, z.tables_per_wg, a.card,   \
+      reduced_body<KT, 2, FUSED_KMAX, READ_RECORDS>(block, E_all, sh, a.views, z.rgs, z.ntables, z.tables_per_wg, a.card, \
                                       a.binom, a.num_rows, a.kind, a.ess, z.G, nullptr, 0.0, nullptr,         \
-                                      a.lg_alpha, z.e_stride, z.wg_rg);                                       \
+                                      a.lg_alpha, z.e_stride, z.wg_rg, z.recs, z.rec_mode);                   \
   } break
   switch (k) {   // uniform over the workgroup
     OBNSL_FUNCTIONAL_CASE(1);
@@ -587,7 +634,13 @@ void launch_score_one(hipStream_t s, const uint32_t* counts, const TableDesc& td
 }
 
 void launch_functional_all(hipStream_t s, uint32_t grid, size_t lds_bytes, const FunctionalAllArgs& a) {
-  hipLaunchKernelGGL(functional_all_kernel, dim3(grid), dim3(64), lds_bytes, s, a);
+  // every size's tables from their records, or every size's from the descriptors
+  bool all_read = true;
+  for (uint32_t k = 1; k <= a.kmax; ++k) all_read = all_read && (a.size[k].rec_mode == 2 || a.size[k].ntables == 0);
+  if (all_read)
+    hipLaunchKernelGGL(functional_all_kernel<true>, dim3(grid), dim3(64), lds_bytes, s, a);
+  else
+    hipLaunchKernelGGL(functional_all_kernel<false>, dim3(grid), dim3(64), lds_bytes, s, a);
 }
 
 void launch_scores_best(hipStream_t s, const ScoresAllArgs& a) {

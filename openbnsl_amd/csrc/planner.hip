@@ -1630,6 +1630,35 @@ obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, u
     Batch* b = lp->batches[0].get();
     if (b->ntables) OB_TRY(scorer_shape(d, lp, j, own_cells, &sh));
     FunctionalSizeArgs& z = fa.size[j];
+    // the tables' records: read when they exist for these count-table layouts, else written
+    // by this launch (not where an offset would not fit its 32 bits, or the records 2 GiB)
+    z.recs = nullptr;
+    z.rec_mode = 0;
+    {
+      const void* key[2 * (KFAST + 1)] = {nullptr};
+      bool fits = !env().no_table_records;
+      for (uint32_t i = 1; i <= j; ++i) {
+        key[2 * i] = fa.views.v[i].rowoff;
+        key[2 * i + 1] = fa.views.v[i].cgs;
+      }
+      for (uint32_t i = 1; i <= j && fits; ++i) {
+        Plan* pi = nullptr;   // the plan whose table size i's view reads
+        for (auto& kv : d->plans)
+          if (kv.second->red.p == fa.views.v[i].red && kv.second->k == i) pi = kv.second.get();
+        if (!pi || pi->batches.empty() || pi->batches[0]->ncells >= (1ull << 32)) fits = false;
+      }
+      const uint64_t words = (uint64_t)b->ntables * table_record_words((int)j);
+      if (fits && b->ntables && words * sizeof(uint32_t) <= (2ull << 30)) {
+        const bool same = lp->recs_ready && std::equal(key, key + 2 * (KFAST + 1), lp->recs_key);
+        if (!same) {
+          HIP_TRY(lp->recs.ensure(words));
+          std::copy(key, key + 2 * (KFAST + 1), lp->recs_key);
+          lp->recs_ready = true;   // (by the launch queued below; later launches follow it on the stream)
+        }
+        z.recs = lp->recs.p;
+        z.rec_mode = same ? 2 : 1;
+      }
+    }
     z.rgs = b->rgs.p;
     z.wg_rg = b->wg_rg.p;
     z.G = lp->G.p;
@@ -1658,6 +1687,15 @@ obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, u
   fa.best_key = d_best_out ? keys : nullptr;
   fa.n = d->n;
   if (grid == 0) return fail(OBNSL_ERR_RUNTIME, "internal: fused scorer without tables");
+  // (a launch reads records only when every size has them: else those that have them
+  // are worked out from the descriptors once more, without being rewritten)
+  {
+    bool all_read = true;
+    for (uint32_t j = 1; j <= kmax; ++j) all_read = all_read && (fa.size[j].rec_mode == 2 || fa.size[j].ntables == 0);
+    if (!all_read)
+      for (uint32_t j = 1; j <= kmax; ++j)
+        if (fa.size[j].rec_mode == 2) fa.size[j].rec_mode = 0;
+  }
   launch_functional_all(d->stream, grid, lds, fa);
   HIP_TRY(hipGetLastError());
   const double N_d = (double)d->N;

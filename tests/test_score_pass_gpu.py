@@ -25,6 +25,19 @@ def _both_ways(engine, torch, codes, card, mp, kind, shard, nshards):
         best = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
         d.precount(mp + 1, shard, nshards)
         if fused:
+            # three passes: the first works every table out from the descriptors (and leaves
+            # the per-table records behind), the later ones read the records
+            prev = None
+            for _ in range(3):
+                for t in tabs:
+                    t.fill_(float("-inf"))
+                d.score_pass(ptrs, mp, best.data_ptr(), kind=kind, ess=1.0, shard=shard, num_shards=nshards)
+                torch.cuda.synchronize()
+                now = [t.cpu().numpy() for t in tabs] + [best.cpu().numpy()]
+                assert prev is None or all(np.array_equal(a, b) for a, b in zip(prev, now))
+                prev = now
+                d.pack()
+                d.precount(mp + 1, shard, nshards)
             d.score_pass(ptrs, mp, best.data_ptr(), kind=kind, ess=1.0, shard=shard, num_shards=nshards)
         else:
             for k in range(1, mp + 2):

@@ -36,7 +36,8 @@ def per_launch(path, counter):
 
 shutil.copy(one(f"gpurun_out/{tag}_trace/*/*kernel_stats.csv"), f"profiles/{name}_kernel_stats.csv")
 shutil.copy(f"gpurun_out/{tag}_bench_under_trace.json", f"profiles/{name}_bench_under_trace.json")
-summary = {"workload": workload, "kernel": dominant, "count_path": "mfma" if "mfma" in dominant else "valu"}
+summary = {"workload": workload, "kernel": dominant,
+           "count_path": "mfma" if "mfma" in dominant else "histogram" if "hist" in dominant else "valu"}
 for r in csv.DictReader(open(f"profiles/{name}_kernel_stats.csv")):
     if dominant in r["Name"]:
         summary["kernel_trace"] = {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]),
