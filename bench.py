@@ -290,6 +290,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="alarm37_1e6_bdeu_mp3", choices=sorted(WORKLOADS))
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="the W + K passes are timed twice: first from the idle device (reported as "
+                         "cold_start), then again after this many milliseconds of untimed passes, when "
+                         "the device has reached its steady speed (0: only the first measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only-hot-path", action="store_true",
                     help="skip the exhaustive-search / annealing wall-clock legs and the CPU baseline "
@@ -350,19 +354,44 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        best = step()
-    data.kernel_time(mp + 1, reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        best = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if exchange:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure():
+        """W untimed passes, then exactly K passes between barriers; the slowest rank's time."""
+        for _ in range(args.warmup):
+            step()
+        data.kernel_time(mp + 1, reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if exchange:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # An MI355X that has been idle takes ~30 ms of load to reach its steady speed (the time
+    # per pass falls by ~10 % over the first 50 passes of the 37-variable workload,
+    # tools/step_ramp.py).  The W + K passes are therefore measured twice: from the idle
+    # device as the command line says (cold_start), and again after settle-ms of untimed
+    # passes -- the steady rate a resident service sees, which is `value`.
+    elapsed = measure()
+    cold = None
+    if args.settle_ms > 0:
+        cold = {"ms_per_step": elapsed / args.steps * 1e3, "value": n_scores * args.steps / elapsed,
+                "unit": "scores/s",
+                "note": "the same W warmup + K timed passes started on the idle device, before the settle passes"}
+        # (a pass count every rank agrees on: from the slowest rank's cold time)
+        settle_steps = max(8, int(args.settle_ms / cold["ms_per_step"]))
+        for i in range(settle_steps):
+            step()
+            if i % 16 == 15:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        cold["settle_ms"] = args.settle_ms
+        cold["settle_steps"] = settle_steps
+        elapsed = measure()
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_scores * args.steps / elapsed
@@ -452,6 +481,7 @@ def main():
                    "world_size": int(dist.get_world_size()) if exchange else 1,
                    "backend": (dist.get_backend() if exchange else None),
                    "sharding": f"subsets split over {world} rank(s) by cost; per-node bests all-gathered"},
+        "cold_start": cold,
         "roofline": roofline,
         # the per-score definition above, kept beside the binding roofline: algorithmic
         # column bytes per second against the HBM peak (the row bitmaps are cache

@@ -142,7 +142,7 @@ struct obnsl_data {
   std::vector<uint32_t> card, plane_base;
   obnsl_internal::DevBuf<uint8_t> codes;
   obnsl_internal::DevBuf<uint32_t> planes, d_card, d_plane_base, counts;
-  obnsl_internal::DevBuf<unsigned long long> best_key;   // per-node arg-max scratch of obnsl_best_parents
+  obnsl_internal::DevBuf<unsigned long long> best_key;   // per-node arg-max scratch of obnsl_best_parents (+ one counter word)
   // scratch of the one-table / explicit-list entry points: grows, never shrinks
   obnsl_internal::DevBuf<uint32_t> one_cnt, list_pb, list_cnt;
   obnsl_internal::DevBuf<obnsl_internal::TableDesc> list_td;
@@ -218,7 +218,7 @@ obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, u
                              uint32_t num_shards, double* const* d_tables, double* d_best_out,
                              unsigned long long* keys);
 obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_scores, uint32_t max_parents,
-                                unsigned long long* keys, bool skip_first_pass);
+                                unsigned long long* keys, bool skip_first_pass, double* decode_out = nullptr);
 uint64_t whole_below(const Plan* p);
 obnsl_status score_all_impl(obnsl_data* d, obnsl_score_kind kind, double ess, uint32_t k, uint32_t shard,
                             uint32_t num_shards, double* scores_out, int out_on_device);
@@ -229,6 +229,7 @@ void launch_gemm_mfma(uint32_t kr, uint32_t kc, uint32_t tile, hipStream_t s, co
                       const MfmaLaunch& l, uint32_t* counts, int flags, int probe);
 void launch_image_scatter(uint32_t tile, hipStream_t s, const uint32_t* images, const uint2* items, uint32_t nitems,
                           const RowDesc* rows, uint32_t nrows, uint32_t* table);
+void launch_image_scatter_parts(hipStream_t s, const ScatterParts& sp);
 bool gemm_mfma_has(uint32_t kr, uint32_t kc, uint32_t tile);
 // gemm_valu.hip
 void launch_gemm_valu(uint32_t kr, uint32_t kc, uint32_t tile, hipStream_t s, const GemmOperands& op,
@@ -281,7 +282,8 @@ void launch_scores_best(hipStream_t s, const ScoresAllArgs& a);
 // kernels_search.hip
 void launch_best_init(hipStream_t s, unsigned long long* keys, unsigned long long* ids, uint32_t n);
 void launch_best_parents(hipStream_t s, const BestArgs& args, uint32_t n, const uint64_t* binom,
-                         unsigned long long* key, unsigned long long* id, int pass);
+                         unsigned long long* key, unsigned long long* id, int pass, double* decode_out = nullptr,
+                         unsigned int* done_counter = nullptr);
 void launch_best_decode(hipStream_t s, const unsigned long long* keys, const unsigned long long* ids, uint32_t n,
                         double* out);
 void launch_best_combine(hipStream_t s, const double* parts, uint32_t world, uint32_t n, double* out);

@@ -1,6 +1,8 @@
 // Plain structs and constants shared by the kernels and the host code that
 // fills them (every translation unit of libobnsl_engine.so); not installed.
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <cstdint>
 
 #include "obnsl_engine.h"
@@ -104,6 +106,20 @@ struct GemmPart {
 };
 struct GemmParts {
   GemmPart p[GEMM_MAX_PARTS - 1];
+};
+
+// The image parts of a launch over several subset sizes, for their one scatter launch.
+struct ScatterPart {
+  const uint32_t* images;
+  const uint2* items;
+  const RowDesc* rows;
+  uint32_t* table;
+  uint32_t nrows, pad_;
+};
+struct ScatterParts {
+  ScatterPart p[GEMM_MAX_PARTS];
+  uint32_t first[GEMM_MAX_PARTS + 1];   // first workgroup of each part; first[nparts] = the grid
+  uint32_t nparts;
 };
 
 // Work list of one matrix-core launch.  unit_start == nullptr: workgroup w works on

@@ -619,6 +619,43 @@ __global__ __launch_bounds__(256) void image_scatter_kernel(
   }
 }
 
+// The same for the image parts of a launch over several subset sizes, in one launch:
+// workgroups [first[p], first[p + 1]) serve part p (128 x 128 tiles).
+__global__ __launch_bounds__(256) void image_scatter_parts_kernel(ScatterParts sp) {
+  constexpr int TB = 128;
+  uint32_t p = 0;
+#pragma unroll
+  for (int j = 1; j < GEMM_MAX_PARTS; ++j)
+    if ((uint32_t)j < sp.nparts && blockIdx.x >= sp.first[j]) p = j;
+  const uint32_t* __restrict__ images = sp.p[0].images;
+  const uint2* __restrict__ items = sp.p[0].items;
+  const RowDesc* __restrict__ rows = sp.p[0].rows;
+  uint32_t* __restrict__ counts = sp.p[0].table;
+  uint32_t nrows = sp.p[0].nrows;
+#pragma unroll
+  for (int j = 1; j < GEMM_MAX_PARTS; ++j)
+    if (p == (uint32_t)j) {
+      images = sp.p[j].images;
+      items = sp.p[j].items;
+      rows = sp.p[j].rows;
+      counts = sp.p[j].table;
+      nrows = sp.p[j].nrows;
+    }
+  const uint32_t block = blockIdx.x - sp.first[p];
+  const uint32_t tile = block / (TB / 8), r8 = block % (TB / 8);
+  const uint2 it = items[tile];
+  const uint32_t rin = r8 * 8 + (threadIdx.x >> 5), lane = threadIdx.x & 31;
+  const uint32_t r = it.x * TB + rin;
+  if (r >= nrows) return;
+  const RowDesc rd = rows[r];
+  const uint32_t* src = images + (size_t)tile * (TB * TB) + rin * TB;
+#pragma unroll
+  for (int cb = 0; cb < TB / 32; ++cb) {
+    const uint32_t c = it.y * TB + cb * 32 + lane;
+    if (c < rd.ncols) counts[rd.out_base + (uint64_t)c * rd.M] = src[cb * 32 + lane];
+  }
+}
+
 template <int KR, int KC, int TB, bool RUNS>
 void launch_form(hipStream_t s, const GemmOperands& op, const MfmaLaunch& l, uint32_t* counts, int flags) {
 #ifdef OBNSL_PROBES
@@ -686,6 +723,10 @@ void launch_image_scatter(uint32_t tile, hipStream_t s, const uint32_t* images, 
   else
     hipLaunchKernelGGL(image_scatter_kernel<128>, dim3(nitems * (128 / 8)), dim3(256), 0, s, images, items, rows,
                        nrows, table);
+}
+
+void launch_image_scatter_parts(hipStream_t s, const ScatterParts& sp) {
+  hipLaunchKernelGGL(image_scatter_parts_kernel, dim3(sp.first[sp.nparts]), dim3(256), 0, s, sp);
 }
 
 }  // namespace obnsl_internal

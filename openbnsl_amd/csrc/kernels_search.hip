@@ -51,7 +51,8 @@ __device__ __forceinline__ uint32_t unrank_step(const uint64_t* __restrict__ bin
 template <int KCAP>
 __global__ __launch_bounds__(256) void best_parents_kernel(
     BestArgs args, uint32_t n, const uint64_t* __restrict__ binom,
-    unsigned long long* __restrict__ best_key, unsigned long long* __restrict__ best_id, int pass) {
+    unsigned long long* __restrict__ best_key, unsigned long long* __restrict__ best_id, int pass,
+    double* __restrict__ decode_out, unsigned int* __restrict__ done_counter) {
   uint32_t k = 1;
 #pragma unroll
   for (int j = 1; j < KMAX; ++j)
@@ -113,6 +114,34 @@ __global__ __launch_bounds__(256) void best_parents_kernel(
       } else if (x != ~0ull) {
         atomicMin(&best_id[v], x);
       }
+    }
+  }
+  // The workgroup that finishes last writes the records (what best_decode_kernel does
+  // in a launch of its own): every workgroup's atomics are visible once it has counted
+  // itself in; the ids are read past this CU's cache.  The counter is left at zero.
+  if (decode_out != nullptr && pass == 1) {
+    __shared__ unsigned int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(done_counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      for (uint32_t v = threadIdx.x; v < n; v += 256) {
+        const unsigned long long kb = __hip_atomic_load(&best_key[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long idv = __hip_atomic_load(&best_id[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kb == 0) {  // nothing scored for this node in this shard
+          decode_out[3 * v] = -INFINITY;
+          decode_out[3 * v + 1] = 0.0;
+          decode_out[3 * v + 2] = 0.0;
+        } else {
+          const unsigned long long bits = (kb >> 63) ? (kb & 0x7fffffffffffffffull) : ~kb;
+          decode_out[3 * v] = __longlong_as_double((long long)bits);
+          decode_out[3 * v + 1] = (double)(idv >> 56);
+          decode_out[3 * v + 2] = (double)(idv & ((1ull << 56) - 1));
+        }
+      }
+      if (threadIdx.x == 0) *done_counter = 0u;
     }
   }
 }
@@ -302,12 +331,15 @@ void launch_best_init(hipStream_t s, unsigned long long* keys, unsigned long lon
 }
 
 void launch_best_parents(hipStream_t s, const BestArgs& args, uint32_t n, const uint64_t* binom,
-                         unsigned long long* key, unsigned long long* id, int pass) {
+                         unsigned long long* key, unsigned long long* id, int pass, double* decode_out,
+                         unsigned int* done_counter) {
   const uint32_t grid = args.block_start[args.kmax];
   if (args.kmax <= (uint32_t)KFAST)
-    hipLaunchKernelGGL(best_parents_kernel<KFAST>, dim3(grid), dim3(256), 0, s, args, n, binom, key, id, pass);
+    hipLaunchKernelGGL(best_parents_kernel<KFAST>, dim3(grid), dim3(256), 0, s, args, n, binom, key, id, pass,
+                       decode_out, done_counter);
   else
-    hipLaunchKernelGGL(best_parents_kernel<KMAX>, dim3(grid), dim3(256), 0, s, args, n, binom, key, id, pass);
+    hipLaunchKernelGGL(best_parents_kernel<KMAX>, dim3(grid), dim3(256), 0, s, args, n, binom, key, id, pass,
+                       decode_out, done_counter);
 }
 
 void launch_best_decode(hipStream_t s, const unsigned long long* keys, const unsigned long long* ids, uint32_t n,

@@ -886,12 +886,26 @@ obnsl_status launch_count_together(obnsl_data* d, std::vector<CountPart>& parts)
       info[4] += cp.b->ncells;
     }
   }
-  for (CountPart& cp : parts)
-    if (cp.image) {
-      launch_image_scatter(cp.plan->tile, d->count_stream(), cp.b->img.p, cp.b->items.p, cp.b->nitems, cp.b->rows.p,
-                           cp.b->nrows, cp.table);
+  {
+    // the finished tile images of every part that used them, into their count tables
+    ScatterParts sp;
+    std::memset(&sp, 0, sizeof(sp));
+    for (CountPart& cp : parts)
+      if (cp.image) {
+        ScatterPart& x = sp.p[sp.nparts];
+        x.images = cp.b->img.p;
+        x.items = cp.b->items.p;
+        x.rows = cp.b->rows.p;
+        x.table = cp.table;
+        x.nrows = cp.b->nrows;
+        sp.first[sp.nparts + 1] = sp.first[sp.nparts] + cp.b->nitems * (128 / 8);
+        ++sp.nparts;
+      }
+    if (sp.nparts) {
+      launch_image_scatter_parts(d->count_stream(), sp);
       HIP_TRY(hipGetLastError());
     }
+  }
   HIP_TRY(hipEventRecord(ev->second, d->count_stream()));
   return OBNSL_OK;
 }
@@ -1504,15 +1518,27 @@ obnsl_status whole_table(obnsl_data* d, uint32_t k, Plan** out) {
 // them), then the pass that picks the smallest (size, rank) among the entries that reach it.
 // `keys`: 2 n words of device memory, keys [0, n), ids [n, 2 n); null = the data set's own
 // buffer (allocated on first use).
+// decode_out (device, 3 n doubles; only with the data set's own buffer): the last workgroup
+// of the second pass writes the records, which saves the launch of best_decode_kernel.
+static obnsl_status own_best_words(obnsl_data* d) {
+  if (d->best_key.n >= 2 * (size_t)d->n + 1) return OBNSL_OK;
+  HIP_TRY(d->best_key.ensure(2 * (size_t)d->n + 1));
+  // (the word behind the keys and ids counts the workgroups that are done: zero between launches)
+  HIP_TRY(hipMemsetAsync(d->best_key.p + 2 * (size_t)d->n, 0, sizeof(unsigned long long), d->stream));
+  return OBNSL_OK;
+}
+
 obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_scores, uint32_t max_parents,
-                                unsigned long long* keys, bool skip_first_pass) {
+                                unsigned long long* keys, bool skip_first_pass, double* decode_out) {
   if (max_parents + 1 > (uint32_t)KMAX || max_parents + 1 > d->n)
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   OB_TRY(set_device(d->device));
   if (!keys) {
-    HIP_TRY(d->best_key.ensure(2 * (size_t)d->n));
+    OB_TRY(own_best_words(d));
     keys = d->best_key.p;
   }
+  if (decode_out && keys != d->best_key.p)
+    return fail(OBNSL_ERR_RUNTIME, "internal: fused record write without the data set's own arg-max words");
   unsigned long long* key = keys;
   unsigned long long* id = keys + d->n;
   if (!skip_first_pass) launch_best_init(d->stream, key, id, d->n);
@@ -1526,7 +1552,8 @@ obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_scores, ui
     args.block_start[k] = args.block_start[k - 1] + (uint32_t)std::min<uint64_t>((nsub + 255) / 256, 512);
   }
   for (int pass = skip_first_pass ? 1 : 0; pass < 2; ++pass)
-    launch_best_parents(d->stream, args, d->n, d->d_binom.p, key, id, pass);
+    launch_best_parents(d->stream, args, d->n, d->d_binom.p, key, id, pass, pass == 1 ? decode_out : nullptr,
+                        decode_out ? reinterpret_cast<unsigned int*>(d->best_key.p + 2 * (size_t)d->n) : nullptr);
   HIP_TRY(hipGetLastError());
   return OBNSL_OK;
 }
@@ -1590,7 +1617,7 @@ obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, u
     return OBNSL_OK;
   }
   if (d_best_out && !keys) {
-    HIP_TRY(d->best_key.ensure(2 * (size_t)d->n));
+    OB_TRY(own_best_words(d));
     keys = d->best_key.p;
   }
   FunctionalAllArgs fa;
@@ -1719,6 +1746,9 @@ obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, u
   }
   if (d_best_out) {
     std::vector<const double*> ptrs(d_tables, d_tables + kmax);
+    // (the records in a launch of their own: with the last workgroup of the tie-break pass
+    // writing them -- queue_best_parents' decode_out -- that pass took 25.8 us instead of
+    // 8.7 + 4.0 for the two launches: every workgroup waits on a device-wide fence first)
     OB_TRY(queue_best_parents(d, ptrs.data(), max_parents, keys, true));
     launch_best_decode(d->stream, keys, keys + d->n, d->n, d_best_out);
     HIP_TRY(hipGetLastError());
