@@ -117,3 +117,35 @@ def test_group_of_one_rank_through_rccl():
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0 and "rccl group ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.skipif("OPENBNSL_TEST_DEVICES" not in os.environ,
+                    reason="bring-up of the exchange between distinct devices: set OPENBNSL_TEST_DEVICES=0,1,...")
+def test_group_over_distinct_devices():
+    """The exchange between DISTINCT devices (grouped RCCL calls over one communicator per
+    device, or peer copies with OBNSL_GROUP_EXCHANGE=copy) against the single-device result.
+    Opt-in: no box this repository was developed on had two GPUs, so this is the first thing
+    to run on one that has -- in a process of its own and under a time limit."""
+    devices = [int(d) for d in os.environ["OPENBNSL_TEST_DEVICES"].split(",")]
+    code = (
+        "import numpy as np, torch\n"
+        "from openbnsl_amd import engine, synth\n"
+        f"devices = {devices!r}\n"
+        "codes, card, _, _ = synth.random_bn([2,3,4,2,3,4,3,2,4,3,2,3,2,4,3,2], 20000, seed=9)\n"
+        "d = engine.Data(codes, card)\n"
+        "tabs = [d.score_all(k) for k in (1, 2, 3, 4)]\n"
+        "dev = [torch.from_numpy(t.reshape(-1)).cuda() for t in tabs]\n"
+        "want = d.best_parents([t.data_ptr() for t in dev], 3)\n"
+        "g = engine.Group(codes, card, devices)\n"
+        "print('group', g.info(), flush=True)\n"
+        "for repack in (True, False, True):\n"
+        "    got = g.best_parents(3, repack=repack)\n"
+        "    assert all(np.array_equal(a, b) for a, b in zip(got, want))\n"
+        "assert all(np.array_equal(a, b) for a, b in zip(g.score_tables(3), tabs))\n"
+        "assert g.exhaustive_search(3) == d.exhaustive_search(3)\n"
+        "assert torch.cuda.current_device() == 0\n"
+        "g.close(); d.close(); print('distinct devices ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "distinct devices ok" in out.stdout, out.stdout + out.stderr

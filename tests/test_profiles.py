@@ -27,11 +27,19 @@ def test_default_summary_matches_the_default_workload():
 def test_matrix_pipe_time_is_below_launch_time_in_every_summary():
     for cfg, workload in ((2, "alarm37_1e6_bdeu_mp3"), (3, "alarm37_1e6_bic_mp4"),
                           (4, "hepar70_1e7_bdeu_mp3"), (5, "uniform128x4_1e7_bdeu_mp3")):
-        s = load("r2_cfg%d_pmc_summary.json" % cfg)
-        assert s["workload"] == workload
-        assert s["mfma"]["busy_cycles_per_instruction"] == 32.0
-        clock_hz = s["clock"]["effective_clock_ghz"] * 1e9
-        pipe_s = s["mfma"]["instructions_per_launch"] * 32 / 1024 / clock_hz   # per SIMD, 1024 SIMDs
-        launch_s = s["clock"]["launch_ns_under_counters"] * 1e-9
-        assert 0.2 < pipe_s / launch_s < 1.0, (cfg, pipe_s, launch_s)
-        assert s["kernel_trace"]["calls"] >= 4
+        for rnd in (2, 3):
+            s = load("r%d_cfg%d_pmc_summary.json" % (rnd, cfg))
+            assert s["workload"] == workload
+            assert s["mfma"]["busy_cycles_per_instruction"] == 32.0
+            clock_hz = s["clock"]["effective_clock_ghz"] * 1e9
+            pipe_s = s["mfma"]["instructions_per_launch"] * 32 / 1024 / clock_hz   # per SIMD, 1024 SIMDs
+            launch_s = s["clock"]["launch_ns_under_counters"] * 1e-9
+            assert 0.2 < pipe_s / launch_s < 1.0, (cfg, pipe_s, launch_s)
+            assert s["kernel_trace"]["calls"] >= (4 if rnd == 2 else 1)
+
+
+def test_histogram_path_summary():
+    """The per-row counting path has its own profile: one launch over many variables."""
+    s = load("r3_hist_pmc_summary.json")
+    assert s["count_path"] != "mfma"
+    assert s["kernel_trace"]["calls"] >= 1
