@@ -294,6 +294,8 @@ def main():
                     help="the W + K passes are timed twice: first from the idle device (reported as "
                          "cold_start), then again after this many milliseconds of untimed passes, when "
                          "the device has reached its steady speed (0: only the first measurement)")
+    ap.add_argument("--sharding", default="auto", choices=["auto", "subsets", "rows"],
+                    help="how several ranks split a pass (auto: the rows of a short pass, else the subsets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only-hot-path", action="store_true",
                     help="skip the exhaustive-search / annealing wall-clock legs and the CPU baseline "
@@ -342,8 +344,10 @@ def main():
     kind = engine.BDEU if spec["score"] == "bdeu" else engine.BIC
 
     hot = HotPath(codes, card, mp, kind=kind, ess=1.0, rank=rank, world=world, device_index=dev_index,
-                  exchange=exchange)
+                  exchange=exchange, sharding=args.sharding)
     data = hot.data
+    rows_mode = hot.sharding == "rows"
+    rows_launch = data.N      # rows one count launch of this rank contracts over (its slice when the rows are split)
     tables = hot.tables
     n_scores = hot.scores_per_pass
     step = hot.step
@@ -411,7 +415,8 @@ def main():
     top_scores_rank = int(torch.isfinite(tables[k_top - 1]).sum().item())
     # algorithmic bytes: N bytes per (child, parent set) score (one uint8
     # column of N rows per score) x the scores one launch yields
-    alg_bytes_per_launch = top_scores_rank * N / launches_per_step
+    # (ranks that split the rows: every score of the size, over the rank's rows)
+    alg_bytes_per_launch = (top_scores_all if rows_mode else top_scores_rank) * rows_launch / launches_per_step
     hbm_alg = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
 
     # HBM traffic of that kernel: PMC counters need rocprofv3 passes of their own
@@ -437,7 +442,7 @@ def main():
         # and a shard counts its share of the cells)
         info = data.count_launch_info(k_top)
         cells = float(info["cells_asked"]) or None
-        flops = 2.0 * cells * N / launches_per_step if cells else None
+        flops = 2.0 * cells * rows_launch / launches_per_step if cells else None
         ach = flops / (kernel_ms * 1e-3) / 1e12 if flops else None
         roofline = {"bound": "mfma", "achieved": ach, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / MFMA_FP4_PEAK_TFLOPS if ach else None, "traffic": traffic,
@@ -480,7 +485,9 @@ def main():
                    "max_parents": mp, "score": spec["score"], "scores_per_step": int(n_scores),
                    "world_size": int(dist.get_world_size()) if exchange else 1,
                    "backend": (dist.get_backend() if exchange else None),
-                   "sharding": f"subsets split over {world} rank(s) by cost; per-node bests all-gathered"},
+                   "sharding": (f"rows split over {world} ranks ({rows_launch} on rank 0); one all-reduce of all "
+                                "count tables; tables scored in shares; per-node bests all-gathered" if rows_mode else
+                                f"subsets split over {world} rank(s) by cost; per-node bests all-gathered")},
         "cold_start": cold,
         "roofline": roofline,
         # the per-score definition above, kept beside the binding roofline: algorithmic

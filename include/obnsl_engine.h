@@ -157,9 +157,32 @@ obnsl_status obnsl_counts_cells(obnsl_data* d, uint32_t k, uint64_t* cells_out);
  * and the acknowledgement that it now holds the sum over the ranks. */
 obnsl_status obnsl_counts_pointer(obnsl_data* d, uint32_t k, uint32_t** d_table_out,
                                   uint64_t* cells_out);
-obnsl_status obnsl_counts_mark_summed(obnsl_data* d, uint32_t k);
+obnsl_status obnsl_counts_mark_summed(obnsl_data* d, uint32_t k); /* k = 0: every size */
 obnsl_status obnsl_counts_export(obnsl_data* d, uint32_t k, uint32_t* d_dst);
 obnsl_status obnsl_counts_import(obnsl_data* d, uint32_t k, const uint32_t* d_src);
+
+/* Ranks that split the ROWS instead of the subsets (no counterpart in the reference,
+ * whose one loop runs over all rows, contingency_table.h:52-55).  For a short pass
+ * -- few tiles per subset size, where a split of the subsets leaves ranks without
+ * work and every rank with the same fixed part -- each rank creates its data set
+ * over a slice of the rows (obnsl_data_create on codes + first_row, the same
+ * col_stride and cardinalities on every rank) and names the rows of the whole
+ * data set once with obnsl_data_set_total_rows.  Per pass: obnsl_data_pack (the
+ * slice only), obnsl_precount_rows -- every subset size 1..kmax counted over the
+ * slice in one launch, the count tables in ONE contiguous range of device memory
+ * (*d_counts_out, *words_out uint32 words, the same layout on every rank) -- one
+ * all-reduce(sum) of that range over the ranks on the data set's stream,
+ * obnsl_counts_mark_summed(d, 0) (0 = every size), then obnsl_score_pass with
+ * (shard, num_shards) = (rank, world): every rank now holds every count and scores
+ * its share of the tables with the total number of rows.  Scoring calls refuse to
+ * run before the sum is acknowledged.  Every size up to kmax must be served by the
+ * bit-plane contraction (else OBNSL_ERR_UNSUPPORTED: counts of the per-row path are
+ * scored as they are produced and never leave the call); the choice is made from
+ * total_rows, so it is the same on every rank.  *words_out = 0: the tables of the
+ * current row bitmaps were counted and summed by an earlier call (nothing to add). */
+obnsl_status obnsl_data_set_total_rows(obnsl_data* d, uint64_t total_rows);
+obnsl_status obnsl_precount_rows(obnsl_data* d, uint32_t kmax, uint32_t** d_counts_out,
+                                 uint64_t* words_out);
 
 /* Inspection of what the batch counting kernel produced (no counterpart in the
  * reference, which keeps one table at a time, contingency_table.h:24-27): the

@@ -86,6 +86,7 @@ obnsl_status obnsl_data_create(const uint8_t* codes, uint64_t num_rows, uint64_t
   d->device = device;
   d->num_cus = (uint32_t)cus;
   d->N = num_rows;
+  d->total_rows = num_rows;
   d->n = num_vars;
   d->card.assign(cardinalities, cardinalities + num_vars);
   d->plane_base.resize(num_vars);
@@ -295,7 +296,31 @@ obnsl_status obnsl_counts_pointer(obnsl_data* d, uint32_t k, uint32_t** d_table_
   return OBNSL_OK;
 }
 
+obnsl_status obnsl_data_set_total_rows(obnsl_data* d, uint64_t total_rows) {
+  if (!d) return fail(OBNSL_ERR_INVALID_ARGUMENT, "data is null");
+  if (total_rows < d->N) return fail(OBNSL_ERR_INVALID_ARGUMENT, "total_rows is smaller than the rows this data set holds");
+  if (total_rows >= (1ull << 32)) return fail(OBNSL_ERR_UNSUPPORTED, "more than 2^32-1 rows");
+  if (total_rows == d->total_rows) return OBNSL_OK;
+  d->total_rows = total_rows;
+  for (auto& kv : d->plans) {   // nothing worked out for the old total survives
+    kv.second->g_epoch = 0;
+    kv.second->counted_epoch = 0;
+    kv.second->zeroed_epoch = 0;
+    kv.second->awaits_sum = false;
+  }
+  return OBNSL_OK;
+}
+
+obnsl_status obnsl_precount_rows(obnsl_data* d, uint32_t kmax, uint32_t** d_counts_out, uint64_t* words_out) {
+  return precount_rows_impl(d, kmax, d_counts_out, words_out);
+}
+
 obnsl_status obnsl_counts_mark_summed(obnsl_data* d, uint32_t k) {
+  if (d && k == 0) {   // every size at once (after the one all-reduce of obnsl_precount_rows)
+    for (auto& kv : d->plans)
+      if (kv.second->counted_epoch == d->epoch) kv.second->awaits_sum = false;
+    return OBNSL_OK;
+  }
   Plan* p = nullptr;
   obnsl_status st = whole_table(d, k, &p);
   if (st != OBNSL_OK) return st;

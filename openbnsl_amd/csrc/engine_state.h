@@ -24,14 +24,23 @@ template <class T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool borrowed = false;   // `p` points into another buffer's memory (not freed here)
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { reset(); }
   void reset() {
-    if (p) (void)hipFree(p);
+    if (p && !borrowed) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    borrowed = false;
+  }
+  // Views `count` elements at `ptr` (memory another buffer owns and outlives this one).
+  void borrow(T* ptr, size_t count) {
+    reset();
+    p = ptr;
+    n = count;
+    borrowed = true;
   }
   hipError_t ensure(size_t count) {
     if (count <= n) return hipSuccess;
@@ -138,6 +147,16 @@ struct obnsl_data {
   uint32_t num_cus = 256;                             // compute units of the device
   hipStream_t stream = nullptr;
   uint64_t N = 0, stride = 0;
+  // Rows of the data set the scores are about.  Larger than N when this handle holds one
+  // rank's slice of the rows: its count tables are then partial sums (Plan::awaits_sum)
+  // until the caller has added them up over the ranks.
+  uint64_t total_rows = 0;
+  bool rows_sharded() const { return total_rows != N; }
+  bool counting_rows = false;   // inside obnsl_precount_rows (the one call that may count a slice)
+  // rows-sharded: the count tables of sizes 1..arena_kmax, contiguous for one all-reduce
+  obnsl_internal::DevBuf<uint32_t> arena;
+  uint32_t arena_kmax = 0;
+  uint64_t arena_words = 0;
   uint32_t n = 0, wp = 0, total_planes = 0, ones_plane = 0;
   std::vector<uint32_t> card, plane_base;
   obnsl_internal::DevBuf<uint8_t> codes;
@@ -214,6 +233,7 @@ obnsl_status run_pack(obnsl_data* d, uint32_t* bad_code = nullptr);
 obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_t num_shards, bool shard_lower,
                            uint32_t* sum_size_out, uint64_t* sum_cells_out);
 obnsl_status whole_table(obnsl_data* d, uint32_t k, Plan** out);
+obnsl_status precount_rows_impl(obnsl_data* d, uint32_t kmax, uint32_t** d_counts_out, uint64_t* words_out);
 obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, uint32_t max_parents, uint32_t shard,
                              uint32_t num_shards, double* const* d_tables, double* d_best_out,
                              unsigned long long* keys);

@@ -23,13 +23,14 @@
 //   OBNSL_RUN_PHASES=a,b,..  shares (percent) of such a launch per phase of runs (default 80,12,8)
 //   OBNSL_RUN_PIECES=a,b,..  runs per workgroup slot in each phase (default 1,1,1)
 //   OBNSL_NO_TOGETHER        one count launch per subset size, never one persistent launch for all sizes
-//   OBNSL_TOGETHER_PHASES=.. / OBNSL_TOGETHER_PIECES=..  phases of that launch (default 65,15,10,10 / 1,1,1,2)
+//   OBNSL_TOGETHER_PHASES=.. / OBNSL_TOGETHER_PIECES=..  phases of that launch (default 65,15,10,10 / 1,1,1,2;
+//                            70,30 and 100 for launches of fewer than 110 / 28 steps per workgroup slot)
 //   OBNSL_RUNS_MAX_STEPS=n   longest launch, in contraction steps per workgroup slot, that takes the form
 //   OBNSL_PROBE=<bits>       timing probes; honoured only by a library built with -DOBNSL_PROBES
 //
 // All of them select among code paths that produce the same counts and scores.
-// (OBNSL_GROUP_EXCHANGE, OBNSL_ANNEAL_SCORES and OMP_NUM_THREADS are read where
-// they apply: group.hip, anneal.cpp.)
+// (OBNSL_GROUP_EXCHANGE, OBNSL_GROUP_SHARDING, OBNSL_ANNEAL_SCORES and OMP_NUM_THREADS are
+// read where they apply: group.hip, anneal.cpp.)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,6 +143,7 @@ Env read_env() {
     if (!ph.empty()) {
       x.together_phases = ph;
       x.together_pieces.assign(ph.size(), 1);
+      x.together_phases_set = true;
     }
     const std::vector<uint32_t> pc = counts_list("OBNSL_TOGETHER_PIECES", x.together_phases.size());
     if (!pc.empty()) x.together_pieces = pc;

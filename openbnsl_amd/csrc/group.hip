@@ -3,9 +3,9 @@
 //
 // The reference is a single-threaded, single-device program
 // (src/structure_learning/exhaustive_search.cpp:47-130 has no parallel loop).
-// Here the subsets of every size are split over the devices of a group; rank r
+// Here the work of a pass is split over the devices of a group; rank r
 // (= devices[r]) holds a replica of the data matrix and works on its own
-// stream.  One pass:
+// stream.  One pass, ranks splitting the SUBSETS:
 //
 //   every rank : pack -> count (largest size: its shard; second largest: its
 //                slice; smaller sizes whole)                       [asynchronous]
@@ -13,6 +13,15 @@
 //   every rank : score its shard of every size -> per-node bests of the shard
 //   exchange 2 : all-gather of the per-node records (3 doubles per node)
 //   every rank : deterministic combine (score, then fewer parents, then rank)
+//
+// A short pass (all count tables of sizes 1..max_parents+1 within 64 MiB, every size on
+// the bit-plane contraction, at least 32768 rows per rank) splits the ROWS instead: a
+// split of the subsets leaves every rank the same fixed part -- the pack of all rows,
+// the small sizes, launch latencies -- and ranks without a tile of the largest size.
+//
+//   every rank : pack ITS rows -> count every size over them (one launch)
+//   exchange 1 : ONE all-reduce(sum, uint32) of all the count tables
+//   every rank : score its share of every size's tables -> as above
 //
 // Every rank has a host thread of its own (its current HIP device set once, to the
 // rank's): the launches of a phase are queued for all ranks at the same time instead
@@ -43,6 +52,7 @@
 #include <vector>
 
 #include "engine_internal.h"
+#include "engine_state.h"
 #include "obnsl_engine.h"
 
 namespace {
@@ -177,6 +187,7 @@ struct Rank {
   int device = 0;
   std::unique_ptr<Worker> worker;
   obnsl_data* data = nullptr;
+  obnsl_data* rows = nullptr;    // this rank's slice of the rows (passes that split the rows)
   hipStream_t stream = nullptr;
   hipEvent_t ready = nullptr, done = nullptr;
   nccl_comm_t comm = nullptr;
@@ -194,6 +205,11 @@ struct Rank {
 struct obnsl_group {
   uint32_t n = 0;
   uint64_t N = 0;
+  std::vector<uint32_t> card;
+  bool no_rows = false;     // OBNSL_GROUP_SHARDING=subsets
+  bool force_rows = false;  // OBNSL_GROUP_SHARDING=rows (wherever the engine can serve it)
+  int rows_served[OBNSL_MAX_SUBSET + 1];   // by kmax: -1 not asked yet, 0 a size is counted per row, 1 yes
+  obnsl_group() { std::fill(rows_served, rows_served + OBNSL_MAX_SUBSET + 1, -1); }
   std::vector<Rank> ranks;
   bool use_rccl = false;
   uint32_t tables_for = 0;  // score tables are allocated for subset sizes 1..tables_for
@@ -205,6 +221,7 @@ struct obnsl_group {
       (void)hipSetDevice(r.device);
       if (r.stream) (void)hipStreamSynchronize(r.stream);
       if (r.comm && rccl().ok()) (void)rccl().CommDestroy(r.comm);
+      if (r.rows) (void)obnsl_data_destroy(r.rows);
       if (r.data) (void)obnsl_data_destroy(r.data);
       for (double* t : r.tables)
         if (t) (void)hipFree(t);
@@ -388,12 +405,91 @@ obnsl_status all_reduce_max_f64(obnsl_group* g, const std::vector<double*>& ptr,
   return fan_out(g);
 }
 
+// Whether a pass over subset sizes 1..kmax splits the rows: a function of the problem
+// only (the same rule as openbnsl_amd/pipeline.py's choose_sharding).
+bool rows_pass(const obnsl_group* g, uint32_t kmax) {
+  const uint64_t W = g->ranks.size();
+  if (W <= 1 || g->no_rows || kmax > 8 || kmax > g->n) return false;
+  std::vector<uint64_t> e(kmax + 1, 0);   // elementary symmetric polynomials of r_v - 1
+  e[0] = 1;
+  for (uint32_t r : g->card)
+    for (uint32_t j = kmax; j >= 1; --j) {
+      e[j] += e[j - 1] * (r - 1);
+      if (e[j] > (1ull << 40)) return false;
+    }
+  uint64_t words = 0;
+  for (uint32_t j = 1; j <= kmax; ++j) words += e[j];
+  std::vector<uint32_t> sorted(g->card);
+  std::sort(sorted.rbegin(), sorted.rend());
+  uint64_t top_cells = 1;
+  for (uint32_t j = 0; j < kmax; ++j) top_cells *= sorted[j];
+  if (top_cells > 4096) return false;
+  if (g->force_rows) return g->N / W >= 1;
+  return words * 4 <= (64ull << 20) && g->N / W >= 32 * 1024;
+}
+
+// The slice data sets, made on first use from each rank's resident copy of the matrix
+// (boundaries on multiples of 2048 rows: 64 bitmap words).
+obnsl_status ensure_row_slices(obnsl_group* g) {
+  const uint64_t W = g->ranks.size();
+  if (g->ranks[0].rows) return OBNSL_OK;
+  auto edge = [&](uint64_t r) -> uint64_t {
+    if (r == W) return g->N;
+    return std::min<uint64_t>(g->N, (g->N * r / W + 1024) / 2048 * 2048);
+  };
+  return on_ranks(g, [&](uint32_t r) -> obnsl_status {
+    Rank& rk = g->ranks[r];
+    const uint64_t lo = edge(r), hi = edge(r + 1);
+    if (hi <= lo) return fail(OBNSL_ERR_INVALID_ARGUMENT, "fewer rows than the group's ranks can share");
+    OB_TRY(obnsl_data_create(rk.data->codes.p + lo, hi - lo, rk.data->stride, g->n, g->card.data(), rk.device,
+                             /*codes_on_device=*/1, &rk.rows));
+    OB_TRY(obnsl_data_set_stream(rk.rows, rk.stream));
+    return obnsl_data_set_total_rows(rk.rows, g->N);
+  });
+}
+
 // pack (optional) -> sharded counting -> exchange 1 -> sharded scoring of sizes 1..kmax
 // (and, with `best`, each rank's per-node records of its shard)
 obnsl_status score_pass(obnsl_group* g, obnsl_score_kind kind, double ess, uint32_t kmax, int repack, bool best) {
   const uint32_t W = (uint32_t)g->ranks.size();
   g->enqueue_ms = 0.0;
   OB_TRY(ensure_tables(g, kmax));
+  bool rows = rows_pass(g, kmax);
+  if (rows) {
+    OB_TRY(ensure_row_slices(g));
+    if (g->rows_served[kmax] < 0) {
+      // (the engine's own choice of counting path, made from the rows of the whole data set)
+      g->rows_served[kmax] = 1;
+      for (uint32_t j = 1; j <= kmax; ++j) {
+        int path = OBNSL_PATH_HISTOGRAM;
+        OB_TRY(obnsl_count_path(g->ranks[0].rows, j, &path));
+        if (path == OBNSL_PATH_HISTOGRAM) g->rows_served[kmax] = 0;
+      }
+    }
+    rows = g->rows_served[kmax] == 1;
+  }
+  if (rows) {
+    std::vector<uint32_t*> ptr(W, nullptr);
+    std::vector<uint64_t> words(W, 0);
+    OB_TRY(on_ranks(g, [&](uint32_t r) -> obnsl_status {
+      Rank& rk = g->ranks[r];
+      if (repack) OB_TRY(obnsl_data_pack(rk.rows));
+      for (uint32_t k = 1; k <= kmax; ++k) {
+        hipLaunchKernelGGL(fill_f64_kernel, dim3(512), dim3(256), 0, rk.stream, rk.tables[k - 1], -INFINITY,
+                           rk.table_len[k - 1]);
+        HIP_TRY(hipGetLastError());
+      }
+      return obnsl_precount_rows(rk.rows, kmax, &ptr[r], &words[r]);
+    }));
+    for (uint32_t r = 1; r < W; ++r)
+      if (words[r] != words[0]) return fail(OBNSL_ERR_RUNTIME, "internal: ranks disagree on the tables to sum");
+    if (words[0]) OB_TRY(all_reduce_sum_u32(g, ptr, words[0]));
+    for (uint32_t r = 0; r < W; ++r) OB_TRY(obnsl_counts_mark_summed(g->ranks[r].rows, 0));
+    return on_ranks(g, [&](uint32_t r) -> obnsl_status {
+      Rank& rk = g->ranks[r];
+      return obnsl_score_pass(rk.rows, kind, ess, kmax - 1, r, W, rk.tables.data(), best ? rk.best : nullptr);
+    });
+  }
   std::vector<uint32_t> sum_size(W, 0);
   std::vector<uint64_t> sum_cells(W, 0);
   OB_TRY(on_ranks(g, [&](uint32_t r) -> obnsl_status {
@@ -440,6 +536,12 @@ obnsl_status obnsl_group_create(const uint8_t* codes, uint64_t num_rows, uint64_
   auto g = std::make_unique<obnsl_group>();
   g->n = num_vars;
   g->N = num_rows;
+  if (!cardinalities) return fail(OBNSL_ERR_INVALID_ARGUMENT, "empty data set");
+  g->card.assign(cardinalities, cardinalities + num_vars);
+  if (const char* sh = std::getenv("OBNSL_GROUP_SHARDING")) {
+    g->no_rows = std::strcmp(sh, "subsets") == 0;
+    g->force_rows = std::strcmp(sh, "rows") == 0;
+  }
   g->ranks.resize(num_devices);
   std::set<int> distinct;
   for (uint32_t r = 0; r < num_devices; ++r) {

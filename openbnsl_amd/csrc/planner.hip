@@ -804,7 +804,26 @@ obnsl_status launch_count_together(obnsl_data* d, std::vector<CountPart>& parts)
     std::stable_sort(tiles.begin(), tiles.end(), [](const TileRef& x, const TileRef& y) { return x.blocks > y.blocks; });
     std::vector<MfmaUnit> units;
     std::vector<uint32_t> unit_start;
-    cut_runs(tiles, steps_total, top_shape.slots, env().together_phases, env().together_pieces, units, unit_start);
+    // The phases after the first even out its runs' times (+- 13 %) and cost every workgroup
+    // one more prologue and flush each: worth it for long runs only.  Measured on the
+    // 37-variable pass over 1/1, 1/2, 1/4 and 1/8 of 10^6 rows (147, 74, 37 and 19 steps per
+    // slot), launch in ms: four phases 0.412 0.242 0.169 0.142, (70, 30) - 0.235 0.133 0.089,
+    // one phase - 0.276 0.145 0.087.
+    std::vector<double> phases = env().together_phases;
+    std::vector<uint32_t> pieces = env().together_pieces;
+    if (!env().together_phases_set) {
+      uint64_t tile_steps = 0;
+      for (const TileRef& t : tiles) tile_steps += steps_total;
+      const uint64_t per_slot = tile_steps / std::max(1u, top_shape.slots);
+      if (per_slot < 28) {
+        phases = {1.0};
+        pieces = {1};
+      } else if (per_slot < 110) {
+        phases = {0.7, 0.3};
+        pieces = {1, 1};
+      }
+    }
+    cut_runs(tiles, steps_total, top_shape.slots, phases, pieces, units, unit_start);
     OB_TRY(check_units(shapes, units, unit_start, steps_total));
     c->nruns = (uint32_t)unit_start.size() - 1;
     c->nworkgroups = std::min(c->nruns, top_shape.slots);
@@ -937,6 +956,10 @@ obnsl_status ensure_counts(obnsl_data* d, Plan* plan) {
     if (plan->pending_lane >= 0) return join_lane(d, plan->pending_lane);
     return OBNSL_OK;
   }
+  if (d->rows_sharded() && !d->counting_rows)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT,
+                "this data set holds a slice of the rows: count with obnsl_precount_rows and sum the "
+                "count tables over the ranks before scoring");
   if (!plan->red.p) {
     HIP_TRY(plan->red.ensure(std::max<uint64_t>(plan->batches[0]->ncells, 1)));
     plan->zeroed_epoch = 0;  // fresh memory: not cleared by any pack
@@ -1024,7 +1047,7 @@ obnsl_status run_functional(obnsl_data* d, Plan* plan, const ReducedViews& views
     sa.tables_per_wg = sh.tpw;
     sa.card = d->d_card.p;
     sa.binom = d->d_binom.p;
-    sa.num_rows = (uint32_t)d->N;
+    sa.num_rows = (uint32_t)d->total_rows;
     sa.kind = (int)kind;
     sa.ess = ess;
     sa.G = plan->G.p;
@@ -1150,8 +1173,11 @@ obnsl_status choose_reduced(obnsl_data* d, uint32_t k, bool* use_reduced, uint64
     e[0] = 1.0;
     for (uint32_t v = 0; v < d->n; ++v)
       for (uint32_t j = std::min(k, v + 1); j >= 1; --j) e[j] += e[j - 1] * (double)(d->card[v] - 1);
-    const double est_bit = e[k] * (double)d->wp * (use_mfma_gemm() ? 2.0e-5 : 6.7e-5);
-    const double est_hist = (double)binom_host(d->n, k) * (double)d->N * 4.5e-4;
+    // (from the rows of the whole data set, so that ranks holding slices of different
+    // lengths take the same path)
+    const double words = d->rows_sharded() ? (double)((d->total_rows + 31) / 32) : (double)d->wp;
+    const double est_bit = e[k] * words * (use_mfma_gemm() ? 2.0e-5 : 6.7e-5);
+    const double est_hist = (double)binom_host(d->n, k) * (double)d->total_rows * 4.5e-4;
     if (est_hist < est_bit) use = false;
   }
   *use_reduced = use;
@@ -1241,7 +1267,7 @@ obnsl_status score_all_impl(obnsl_data* d, obnsl_score_kind kind, double ess, ui
     ReducedViews views;
     std::memset(&views, 0, sizeof(views));
     Plan* own = nullptr;     // lists this shard's tables
-    const double N_d = (double)d->N;
+    const double N_d = (double)d->total_rows;
     const double g0 = kind == OBNSL_SCORE_BDEU ? std::lgamma(N_d + ess) - std::lgamma(ess)
                                                : N_d * std::log(N_d);
     const double* gprev = nullptr;
@@ -1287,6 +1313,9 @@ obnsl_status score_all_impl(obnsl_data* d, obnsl_score_kind kind, double ess, ui
     }
     st = run_functional(d, own, views, k, max_cells, kind, ess, gprev, g0, d_scores);
     if (st != OBNSL_OK) return st;
+  } else if (d->rows_sharded()) {
+    return fail(OBNSL_ERR_UNSUPPORTED,
+                "a data set that holds a slice of the rows serves subset sizes of the bit-plane contraction only");
   } else if (!env().force_bitgemm || k > (uint32_t)KFAST) {
     // large tables: per-row LDS histograms over this shard's contiguous rank range
     const uint64_t lo = nsub / num_shards * shard + std::min<uint64_t>(shard, nsub % num_shards);
@@ -1499,6 +1528,82 @@ obnsl_status precount_impl(obnsl_data* d, uint32_t kmax, uint32_t shard, uint32_
   return st;
 }
 
+// Ranks that split the ROWS: every subset size 1..kmax counted whole over this handle's
+// slice, the tables in one contiguous range of device memory (so that one all-reduce sums
+// them over the ranks), each marked as a partial sum until the caller acknowledges the sum.
+obnsl_status precount_rows_impl(obnsl_data* d, uint32_t kmax, uint32_t** d_counts_out, uint64_t* words_out) {
+  if (!d || !d_counts_out || !words_out) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
+  *d_counts_out = nullptr;
+  *words_out = 0;
+  if (kmax == 0 || kmax > (uint32_t)KMAX || kmax > d->n)
+    return fail(OBNSL_ERR_INVALID_ARGUMENT, "subset size must be in [1, min(num_vars, OBNSL_MAX_SUBSET)]");
+  OB_TRY(set_device(d->device));
+  for (uint32_t j = 1; j <= kmax; ++j) {
+    bool red = false;
+    OB_TRY(choose_reduced(d, j, &red, nullptr));
+    if (!red)
+      return fail(OBNSL_ERR_UNSUPPORTED, "subset size " + std::to_string(j) +
+                                             " is counted per row on this data set: its tables cannot be "
+                                             "summed over ranks that split the rows");
+  }
+  OB_TRY(join_side(d));
+  std::vector<Plan*> whole(kmax + 1, nullptr);
+  for (uint32_t j = 1; j <= kmax; ++j) OB_TRY(build_plan(d, j, 0, 1, true, &whole[j]));
+  if (d->arena_kmax != kmax) {
+    std::vector<uint64_t> off(kmax + 1, 0);
+    uint64_t total = 0;
+    for (uint32_t j = 1; j <= kmax; ++j) {
+      off[j] = total;
+      total += (std::max<uint64_t>(whole[j]->batches[0]->ncells, 1) + 63) / 64 * 64;
+    }
+    HIP_TRY(hipStreamSynchronize(d->stream));   // nothing in flight reads the tables being replaced
+    for (auto& kv : d->plans) {
+      Plan* p = kv.second.get();
+      if (p->red.borrowed) {
+        p->red.reset();
+        p->counted_epoch = 0;
+      }
+    }
+    d->arena.reset();
+    HIP_TRY(d->arena.ensure(total));
+    HIP_TRY(hipMemset(d->arena.p, 0, total * sizeof(uint32_t)));
+    for (uint32_t j = 1; j <= kmax; ++j) {
+      whole[j]->red.borrow(d->arena.p + off[j], std::max<uint64_t>(whole[j]->batches[0]->ncells, 1));
+      whole[j]->counted_epoch = 0;
+      whole[j]->zeroed_epoch = d->epoch;   // cleared just now
+    }
+    d->arena_kmax = kmax;
+    d->arena_words = total;
+  }
+  std::vector<uint64_t> before(kmax + 1, 0);
+  for (uint32_t j = 1; j <= kmax; ++j) before[j] = whole[j]->counted_epoch;
+  uint32_t fresh = 0, owing = 0;
+  d->counting_rows = true;
+  obnsl_status st = precount_impl(d, kmax, 0, 1, false, nullptr, nullptr);
+  d->counting_rows = false;
+  if (st != OBNSL_OK) return st;
+  for (uint32_t j = 1; j <= kmax; ++j) {
+    if (whole[j]->counted_epoch != d->epoch) {   // (precount leaves nothing out; keep the table honest if it did)
+      d->counting_rows = true;
+      st = ensure_counts(d, whole[j]);
+      d->counting_rows = false;
+      if (st != OBNSL_OK) return st;
+    }
+    if (whole[j]->counted_epoch != before[j]) {
+      ++fresh;
+      if (d->rows_sharded()) whole[j]->awaits_sum = true;
+    }
+    if (whole[j]->awaits_sum) ++owing;
+  }
+  if (fresh != 0 && fresh != kmax)
+    return fail(OBNSL_ERR_RUNTIME, "internal: some count tables of a row slice are older than others");
+  OB_TRY(join_side(d));   // what the caller queues on the data set's stream next sees every table
+  *d_counts_out = d->arena.p;
+  // nothing to sum: the tables of these row bitmaps were counted and summed before
+  *words_out = (fresh == 0 && owing == 0 && d->rows_sharded()) ? 0 : d->arena_words;
+  return OBNSL_OK;
+}
+
 // The whole reduced count table of subset size k, for the export / import pair.
 obnsl_status whole_table(obnsl_data* d, uint32_t k, Plan** out) {
   if (!d) return fail(OBNSL_ERR_INVALID_ARGUMENT, "null argument");
@@ -1707,7 +1812,7 @@ obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, u
   fa.kmax = kmax;
   fa.card = d->d_card.p;
   fa.binom = d->d_binom.p;
-  fa.num_rows = (uint32_t)d->N;
+  fa.num_rows = (uint32_t)d->total_rows;
   fa.kind = (int)kind;
   fa.ess = ess;
   fa.lg_alpha = lg_alpha;
@@ -1725,13 +1830,13 @@ obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, u
   }
   launch_functional_all(d->stream, grid, lds, fa);
   HIP_TRY(hipGetLastError());
-  const double N_d = (double)d->N;
+  const double N_d = (double)d->total_rows;
   sa.g0 = kind == OBNSL_SCORE_BDEU ? std::lgamma(N_d + ess) - std::lgamma(ess) : N_d * std::log(N_d);
   sa.kmax = kmax;
   sa.card = d->d_card.p;
   sa.binom = d->d_binom.p;
   sa.n = d->n;
-  sa.num_rows = (uint32_t)d->N;
+  sa.num_rows = (uint32_t)d->total_rows;
   sa.kind = (int)kind;
   sa.best_key = d_best_out ? keys : nullptr;
   sa.block_start[1] = 0;

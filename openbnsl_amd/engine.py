@@ -48,6 +48,8 @@ SIGNATURES = {
     "obnsl_counts_cells": (ctypes.c_int, [_vp, ctypes.c_uint32, _u64p]),
     "obnsl_counts_pointer": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.POINTER(_vp), _u64p]),
     "obnsl_counts_mark_summed": (ctypes.c_int, [_vp, ctypes.c_uint32]),
+    "obnsl_data_set_total_rows": (ctypes.c_int, [_vp, ctypes.c_uint64]),
+    "obnsl_precount_rows": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
     "obnsl_counts_export": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
     "obnsl_counts_import": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
     "obnsl_reduced_table": (ctypes.c_int, [_vp, _u32p, ctypes.c_uint32, _u32p, ctypes.c_uint64]),
@@ -200,9 +202,11 @@ def load_scores(path):
 
 class Data:
     """Device-resident data set (obnsl_data).  `codes`: uint8[n_vars, N] numpy
-    array (host) or a (device_ptr, n_vars, N, col_stride) tuple."""
+    array (host) or a (device_ptr, n_vars, N, col_stride) tuple.  total_rows: the rows
+    of the whole data set when `codes` is one rank's slice of them (ranks that split
+    the rows: precount_rows, all-reduce, counts_mark_summed(0), score_pass)."""
 
-    def __init__(self, codes, card, device=0):
+    def __init__(self, codes, card, device=0, total_rows=None):
         card = np.ascontiguousarray(card, dtype=np.uint32)
         self._h = _vp()
         if isinstance(codes, tuple):
@@ -217,6 +221,19 @@ class Data:
         self.n, self.N, self.card, self.device = int(n), int(N), card, device
         _check(lib.obnsl_data_create(ptr, N, stride, n, card.ctypes.data_as(_u32p), device,
                                      on_dev, ctypes.byref(self._h)))
+        if total_rows is not None:
+            self.set_total_rows(total_rows)
+
+    def set_total_rows(self, total_rows):
+        _check(lib.obnsl_data_set_total_rows(self._h, int(total_rows)))
+
+    def precount_rows(self, kmax):
+        """Counts every subset size 1..kmax over this handle's rows; returns (device
+        address, uint32 words) of the one range that holds all the count tables."""
+        ptr = _vp()
+        words = ctypes.c_uint64(0)
+        _check(lib.obnsl_precount_rows(self._h, kmax, ctypes.byref(ptr), ctypes.byref(words)))
+        return ptr.value, words.value
 
     def close(self):
         if self._h:

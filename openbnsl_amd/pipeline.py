@@ -1,10 +1,17 @@
 """The whole hot path as one object: what one rank does per pass.
 
+  ranks split the SUBSETS (long passes: many tiles per subset size)
     pack -> count (largest size: this rank's shard; second largest: this rank's
     slice, then all-reduce of that count table; smaller sizes whole) -> for
     k = 1..max_parents+1 score this rank's shard of the size-k subsets ->
     per-node best parent sets of the shard -> (world > 1) all-gather of those
     records and the deterministic combine.
+
+  ranks split the ROWS (short passes: the count tables are small, and a split of
+  the subsets would leave every rank with the same fixed part and some without work)
+    pack this rank's rows -> count every size over them in one launch -> ONE
+    all-reduce of all the count tables -> score this rank's share of the tables ->
+    per-node bests -> all-gather and combine as above.
 
 Used by bench.py (timed) and by the multi-rank tests.  PyTorch provides the
 device score tables, the stream and torch.distributed; every kernel launched is
@@ -23,13 +30,51 @@ class _DeviceInts:
                                          "version": 2, "strides": None}
 
 
+ROWS_MAX_TABLE_BYTES = 64 << 20    # all count tables of a pass, for one all-reduce
+ROWS_MIN_PER_RANK = 32 * 1024      # 32 contraction steps
+
+
+def row_slice(num_rows, rank, world):
+    """[lo, hi) of rank's rows: boundaries on multiples of 2048 rows (64 bitmap words,
+    the padding unit of a data set), the last rank takes what is left."""
+    def edge(r):
+        return num_rows if r == world else min(num_rows, (num_rows * r // world + 1024) // 2048 * 2048)
+    return edge(rank), edge(rank + 1)
+
+
+def count_table_words(card, kmax):
+    """uint32 counters of all count tables of subset sizes 1..kmax (states 1..r-1 of every
+    variable: the elementary symmetric polynomials of r_v - 1), and the largest full table."""
+    e = [1] + [0] * kmax
+    for r in card:
+        for j in range(kmax, 0, -1):
+            e[j] += e[j - 1] * (int(r) - 1)
+    top = sorted((int(r) for r in card), reverse=True)[:kmax]
+    return sum(e[1:]), int(np.prod(top, dtype=np.int64))
+
+
+def choose_sharding(card, num_rows, max_parents, world):
+    """'rows' where a pass is short enough that all its count tables are cheap to all-reduce
+    (and every size goes through the bit-plane contraction), else 'subsets'.  A function of
+    the problem only, so every rank takes the same decision."""
+    kmax = max_parents + 1
+    if world <= 1 or kmax > 8 or kmax > len(card):
+        return "subsets"
+    words, top_cells = count_table_words(card, kmax)
+    if top_cells > 4096 or words * 4 > ROWS_MAX_TABLE_BYTES or num_rows // world < ROWS_MIN_PER_RANK:
+        return "subsets"
+    return "rows"
+
+
 class HotPath:
     def __init__(self, codes, card, max_parents, kind=engine.BDEU, ess=1.0, rank=0, world=1,
-                 device_index=0, exchange=None, fused=True):
+                 device_index=0, exchange=None, fused=True, sharding="auto"):
         """exchange: run the all-gather + combine even in a world of one rank
         (default: only when world > 1).  fused: score every subset size and reduce to the
         per-node bests with one obnsl_score_pass call (False: one obnsl_score_all per size
-        and obnsl_best_parents_device, the same results)."""
+        and obnsl_best_parents_device, the same results).  sharding: 'subsets', 'rows' or
+        'auto' (choose_sharding); `codes` is the whole matrix either way -- in 'rows' mode
+        only this rank's slice of it goes to the device."""
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
@@ -37,9 +82,27 @@ class HotPath:
         self.fused = bool(fused)
         self.dev = torch.device("cuda", device_index)
         torch.cuda.set_device(self.dev)
-        self.data = engine.Data(codes, card, device=device_index)
+        total_rows = int(codes.shape[1])
+        if sharding == "auto":
+            sharding = choose_sharding(card, total_rows, max_parents, world)
+        if sharding not in ("subsets", "rows"):
+            raise ValueError("sharding must be 'subsets', 'rows' or 'auto'")
+        if world == 1:
+            sharding = "subsets"
+        self.sharding = sharding
+        if sharding == "rows":
+            lo, hi = row_slice(total_rows, rank, world)
+            if hi <= lo:
+                raise ValueError("fewer rows than ranks can share")
+            self.data = engine.Data(codes[:, lo:hi], card, device=device_index, total_rows=total_rows)
+            # the engine's own choice of counting path (made from total_rows: the same on every rank)
+            if any(self.data.count_path(k) == "histogram" for k in range(1, max_parents + 2)):
+                self.data.close()
+                self.sharding = sharding = "subsets"
+        if sharding == "subsets":
+            self.data = engine.Data(codes, card, device=device_index)
         self.data.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.n, self.N = self.data.n, self.data.N
+        self.n, self.N = self.data.n, total_rows
         # one score table per subset size; entries of other ranks' shards stay -inf
         self.tables = [torch.full((self.data.num_subsets(k) * k,), float("-inf"),
                                   dtype=torch.float64, device=self.dev)
@@ -62,7 +125,12 @@ class HotPath:
         torch = self.torch
         d = self.data
         d.pack()
-        if self.world > 1 and self.exchange:
+        if self.sharding == "rows":
+            ptr, words = d.precount_rows(self.mp + 1)
+            if self.exchange and words:
+                self._sum_range(ptr, words)
+            d.counts_mark_summed(0)
+        elif self.world > 1 and self.exchange:
             # the second-largest size is counted in slices too; its table is summed
             # over the ranks before anything is scored from it
             size, cells = d.precount_sharded(self.mp + 1, self.rank, self.world)
@@ -96,12 +164,9 @@ class HotPath:
         d.combine_best_device(self.gathered.data_ptr(), self.world, self.combined.data_ptr())
         return self.combined
 
-    def _sum_counts(self, size, cells):
-        """All-reduce of the engine's count table.  In place when torch can alias
-        the table's device memory (CUDA array interface); otherwise through a
-        buffer of torch's own and two device copies."""
+    def _view(self, ptr, cells):
+        """int32 torch view of engine memory (False where torch cannot alias it)."""
         torch = self.torch
-        ptr, cells = self.data.counts_pointer(size)
         view = self._count_views.get((ptr, cells))
         if view is None:
             try:
@@ -111,6 +176,22 @@ class HotPath:
             except Exception:  # noqa: BLE001  (no array-interface support: take the copying path)
                 view = False
             self._count_views[(ptr, cells)] = view
+        return view
+
+    def _sum_range(self, ptr, words):
+        """All-reduce, in place, of the one range that holds every count table."""
+        view = self._view(ptr, words)
+        if view is False:
+            raise RuntimeError("torch cannot alias the engine's count tables on this build")
+        obd.sum_count_table(view)
+
+    def _sum_counts(self, size, cells):
+        """All-reduce of the engine's count table.  In place when torch can alias
+        the table's device memory (CUDA array interface); otherwise through a
+        buffer of torch's own and two device copies."""
+        torch = self.torch
+        ptr, cells = self.data.counts_pointer(size)
+        view = self._view(ptr, cells)
         if view is not False:
             obd.sum_count_table(view)   # disjoint slices, zero elsewhere: the sum is the whole table
             self.data.counts_mark_summed(size)

@@ -45,6 +45,42 @@ def test_group_best_parents_and_tables_equal_single_device(data30, world):
     g.close()
 
 
+@pytest.mark.parametrize("world", [3, 8])
+def test_group_that_splits_the_rows_equals_single_device(world):
+    """A short pass splits the rows over the ranks (every rank counts every size over its
+    rows, one sum of all count tables, every rank scores its share).  The rule asks for
+    32768 rows per rank; OBNSL_GROUP_SHARDING=rows (read when the group is created) applies
+    the split to this smaller data set."""
+    import torch
+    cards = [2, 3, 4, 2, 3, 4, 3, 2, 4, 3, 2, 3, 4, 2, 3, 3]
+    codes, card, _, _ = synth.random_bn(cards, 100_003, seed=43)
+    mp = 3
+    one = engine.Data(codes, card)
+    tabs = [one.score_all(k) for k in range(1, mp + 2)]
+    dev = [torch.from_numpy(t.reshape(-1)).cuda() for t in tabs]
+    want = one.best_parents([t.data_ptr() for t in dev], mp)
+    search = one.exhaustive_search(mp)
+    one.close()
+    os.environ["OBNSL_GROUP_SHARDING"] = "rows"
+    try:
+        g = engine.Group(codes, card, [0] * world)
+    finally:
+        del os.environ["OBNSL_GROUP_SHARDING"]
+    for repack in (False, True, False):           # first pass, fresh bitmaps, cached (already summed) counts
+        got = g.best_parents(mp, repack=repack)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    for a, b in zip(g.score_tables(mp), tabs):
+        assert np.array_equal(a, b)
+    assert g.exhaustive_search(mp) == search
+    # a size the engine counts per row cannot be summed over row slices: the subsets are split instead
+    got2 = g.best_parents(1, repack=True)
+    one = engine.Data(codes, card)
+    dev2 = [torch.from_numpy(one.score_all(k).reshape(-1)).cuda() for k in (1, 2)]
+    assert all(np.array_equal(a, b) for a, b in zip(got2, one.best_parents([t.data_ptr() for t in dev2], 1)))
+    one.close()
+    g.close()
+
+
 def test_group_ranks_are_queued_from_their_own_host_threads(data30):
     """Host time of a pass (the launches of every rank queued, not the devices' work): every
     rank has a host thread, so eight ranks must not cost eight single-rank passes on the

@@ -1,6 +1,7 @@
-"""GPU, two ranks on ONE device: the sharded hot path end to end.  Each rank
-scores its shard of every subset size, reduces to per-node bests, the ranks
-exchange them over gloo (host tensors; RCCL needs one GPU per rank) and the
+"""GPU, several ranks on ONE device: the sharded hot path end to end, with the ranks
+splitting the subsets (each counts and scores its shard of every subset size) or the rows
+(each counts every size over its rows, one all-reduce of all count tables, each scores its
+share).  The ranks exchange over gloo (host tensors; RCCL needs one GPU per rank) and the
 combined result must equal the single-rank result and the oracle's."""
 import os
 import socket
@@ -11,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, sharding):
     import torch.distributed as dist
     import oracle
     from openbnsl_amd import synth
@@ -22,7 +23,8 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     codes, card, _, _ = synth.random_bn([2, 3, 4, 2, 3, 4, 3, 2, 4, 3, 2], 30_000, seed=21)
     mp = 3
-    hot = HotPath(codes, card, mp, rank=rank, world=world, device_index=0)
+    hot = HotPath(codes, card, mp, rank=rank, world=world, device_index=0, sharding=sharding)
+    assert hot.sharding == sharding
     got = None
     for _ in range(2):                       # second pass exercises the cached plans
         got = hot.to_host(hot.step())
@@ -37,7 +39,8 @@ def _worker(rank, world, port, q):
     q.put((rank, bool(ok), mine))
 
 
-def test_two_ranks_one_gpu():
+@pytest.mark.parametrize("sharding", ["subsets", "rows"])
+def test_two_ranks_one_gpu(sharding):
     import torch.multiprocessing as mp
     from openbnsl_amd import engine
     with socket.socket() as s:
@@ -45,7 +48,7 @@ def test_two_ranks_one_gpu():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sharding)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in procs)
@@ -93,7 +96,7 @@ def test_large_tile_instances_still_count_exactly():
     assert "smoke ok" in out.stdout
 
 
-def _full_size_worker(rank, world, port, q, workload):
+def _full_size_worker(rank, world, port, q, workload, sharding):
     """One rank of a benchmark workload at its own size (ranks share the one GPU,
     gloo on host copies): the sharded pass twice, then rank 0 runs the same pass
     unsharded and compares the combined per-node best parent sets."""
@@ -109,7 +112,8 @@ def _full_size_worker(rank, world, port, q, workload):
     codes, card, _ = bench.make_data(spec)
     kind = engine.BDEU if spec["score"] == "bdeu" else engine.BIC
     mp = spec["max_parents"]
-    hot = HotPath(codes, card, mp, kind=kind, rank=rank, world=world, device_index=0)
+    hot = HotPath(codes, card, mp, kind=kind, rank=rank, world=world, device_index=0, sharding=sharding)
+    assert hot.sharding == sharding
     best = None
     for _ in range(2):
         best = hot.step()
@@ -131,9 +135,13 @@ def _full_size_worker(rank, world, port, q, workload):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("workload,world", [("alarm37_1e6_bdeu_mp3", 2), ("alarm37_1e6_bdeu_mp3", 8),
-                                            ("alarm37_1e6_bic_mp4", 4)])
-def test_benchmark_workload_sharded_equals_unsharded(workload, world):
+@pytest.mark.parametrize("workload,world,sharding", [("alarm37_1e6_bdeu_mp3", 2, "subsets"),
+                                                     ("alarm37_1e6_bdeu_mp3", 8, "subsets"),
+                                                     ("alarm37_1e6_bic_mp4", 4, "subsets"),
+                                                     ("alarm37_1e6_bdeu_mp3", 2, "rows"),
+                                                     ("alarm37_1e6_bdeu_mp3", 8, "rows"),
+                                                     ("alarm37_1e6_bic_mp4", 4, "rows")])
+def test_benchmark_workload_sharded_equals_unsharded(workload, world, sharding):
     """Every score covered exactly once over the ranks; combined best parent sets
     identical (scores bit for bit, sizes, ranks) to the unsharded pass."""
     import torch.multiprocessing as mp
@@ -142,10 +150,11 @@ def test_benchmark_workload_sharded_equals_unsharded(workload, world):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_full_size_worker, args=(r, world, port, q, workload)) for r in range(world)]
+    procs = [ctx.Process(target=_full_size_worker, args=(r, world, port, q, workload, sharding)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=400) for _ in procs)
     for p in procs:
         p.join(timeout=60)
     assert res == [(r, True) for r in range(world)]
+
