@@ -14,8 +14,9 @@
 //   exchange 2 : all-gather of the per-node records (3 doubles per node)
 //   every rank : deterministic combine (score, then fewer parents, then rank)
 //
-// A short pass (all count tables of sizes 1..max_parents+1 within 64 MiB, every size on
-// the bit-plane contraction, at least 32768 rows per rank) splits the ROWS instead: a
+// A pass whose count tables (sizes 1..max_parents+1, every size on the bit-plane
+// contraction) are cheap to all-reduce next to its counting time (rows_pass below; at most
+// 64 MiB, at least 32768 rows per rank) splits the ROWS instead: a
 // split of the subsets leaves every rank the same fixed part -- the pack of all rows,
 // the small sizes, launch latencies -- and ranks without a tile of the largest size.
 //
@@ -425,7 +426,13 @@ bool rows_pass(const obnsl_group* g, uint32_t kmax) {
   for (uint32_t j = 0; j < kmax; ++j) top_cells *= sorted[j];
   if (top_cells > 4096) return false;
   if (g->force_rows) return g->N / W >= 1;
-  return words * 4 <= (64ull << 20) && g->N / W >= 32 * 1024;
+  if (words * 4 > (64ull << 20) || g->N / W < 32 * 1024) return false;
+  // one all-reduce of all count tables (0.02 ms + bytes / 150 GB/s) against what a split of
+  // the subsets cannot shard or balance (0.10 ms + 10 % of a rank's share of the counting
+  // time, cells x 32-row words x 2.0e-5 ns)
+  const double allreduce_ms = 0.02 + (double)words * 4.0 / 150e9 * 1e3;
+  const double count_ms = (double)words * (double)((g->N + 31) / 32) * 2.0e-5 * 1e-6;
+  return allreduce_ms <= 0.10 + 0.10 * count_ms / (double)W;
 }
 
 // The slice data sets, made on first use from each rank's resident copy of the matrix

@@ -54,16 +54,27 @@ def count_table_words(card, kmax):
 
 
 def choose_sharding(card, num_rows, max_parents, world):
-    """'rows' where a pass is short enough that all its count tables are cheap to all-reduce
-    (and every size goes through the bit-plane contraction), else 'subsets'.  A function of
-    the problem only, so every rank takes the same decision."""
+    """'rows' or 'subsets': a function of the problem only, so every rank takes the same
+    decision without a collective (obnsl_group_* applies the same rule, group.hip).
+
+    Splitting the rows costs one all-reduce of ALL count tables (estimated at 0.02 ms +
+    bytes / 150 GB/s; splitting the subsets sums the second-largest table only) and saves
+    what a split of the subsets cannot shard or balance: the pack of all rows, the small
+    sizes, and the uneven cost of its shards -- put at 0.10 ms + 10 % of a rank's share of
+    the counting time (cells x 32-row words x 2.0e-5 ns, the engine's own cost model).
+    Measured per-rank times behind the rule (slowest rank, no collective, MI355X):
+    37 variables x 10^6 rows, <= 3 parents (3.1 MB of tables), 8 ranks: 0.145 ms rows,
+    0.284 subsets; <= 4 parents (38 MB): 0.94 against 1.03; 70 variables x 10^7 rows
+    (16 MB): 2.46 against 3.90."""
     kmax = max_parents + 1
     if world <= 1 or kmax > 8 or kmax > len(card):
         return "subsets"
     words, top_cells = count_table_words(card, kmax)
     if top_cells > 4096 or words * 4 > ROWS_MAX_TABLE_BYTES or num_rows // world < ROWS_MIN_PER_RANK:
         return "subsets"
-    return "rows"
+    allreduce_ms = 0.02 + words * 4 / 150e9 * 1e3
+    count_ms = words * ((num_rows + 31) // 32) * 2.0e-5 * 1e-6
+    return "rows" if allreduce_ms <= 0.10 + 0.10 * count_ms / world else "subsets"
 
 
 class HotPath:
