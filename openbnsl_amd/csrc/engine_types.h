@@ -16,6 +16,7 @@ constexpr int KCW = 32;                 // 32-bit words of the contraction per L
 constexpr int LDS_STRIDE = KCW + 4;     // padded slab row (words): conflict-free b128 reads
 constexpr uint64_t BATCH_CELL_CAP = 1ull << 30;  // counters per batch (4 GiB)
 constexpr uint64_t REDUCED_MAX_CELLS = 4096;     // largest full table the reduced-mode scorer expands in LDS
+constexpr int LG_SMALL = 16;   // counts below this take lgamma(n + a) - lgamma(a) from a table (per prior a)
 constexpr int MAX_DEVICES = 64;
 
 constexpr int MFMA_TILE = 128;        // tile edge of the matrix-core kernel (256 for launches of many tiles)

@@ -1012,14 +1012,25 @@ static obnsl_status scorer_shape(obnsl_data* d, Plan* plan, uint32_t k, uint64_t
   return OBNSL_OK;
 }
 
-// lgamma(ess / c) for c = 1..REDUCED_MAX_CELLS on the device (from the host's libm, per ess).
+// Per ess, on the device (from the host's libm): lgamma(ess / c) for c = 1..REDUCED_MAX_CELLS
+// at index c, and behind those, at (REDUCED_MAX_CELLS + 1) + c * LG_SMALL + n, the difference
+// lgamma(n + ess / c) - lgamma(ess / c) = sum_{i < n} ln(ess / c + i) for n < LG_SMALL.
 static obnsl_status lg_alpha_table(obnsl_data* d, obnsl_score_kind kind, double ess, const double** out) {
   *out = nullptr;
   if (kind != OBNSL_SCORE_BDEU) return OBNSL_OK;
   auto& slot = d->lg_alpha[ess];
   if (!slot) {
-    std::vector<double> h(REDUCED_MAX_CELLS + 1, 0.0);
-    for (uint64_t c = 1; c <= REDUCED_MAX_CELLS; ++c) h[c] = std::lgamma(ess / (double)c);
+    std::vector<double> h((REDUCED_MAX_CELLS + 1) * (1 + LG_SMALL), 0.0);
+    for (uint64_t c = 1; c <= REDUCED_MAX_CELLS; ++c) {
+      const double a = ess / (double)c;
+      h[c] = std::lgamma(a);
+      double* small = h.data() + (REDUCED_MAX_CELLS + 1) + c * LG_SMALL;
+      double acc = 0.0;
+      for (int n = 1; n < LG_SMALL; ++n) {
+        acc += std::log(a + (double)(n - 1));
+        small[n] = acc;
+      }
+    }
     slot = std::make_unique<DevBuf<double>>();
     HIP_TRY(slot->upload(h));
   }
@@ -1566,7 +1577,9 @@ obnsl_status precount_rows_impl(obnsl_data* d, uint32_t kmax, uint32_t** d_count
     }
     d->arena.reset();
     HIP_TRY(d->arena.ensure(total));
-    HIP_TRY(hipMemset(d->arena.p, 0, total * sizeof(uint32_t)));
+    // (on the data set's stream: a fill on the null stream is not ordered before the count
+    // launches of a non-blocking stream)
+    HIP_TRY(hipMemsetAsync(d->arena.p, 0, total * sizeof(uint32_t), d->stream));
     for (uint32_t j = 1; j <= kmax; ++j) {
       whole[j]->red.borrow(d->arena.p + off[j], std::max<uint64_t>(whole[j]->batches[0]->ncells, 1));
       whole[j]->counted_epoch = 0;

@@ -98,9 +98,7 @@ class HotPath:
             sharding = choose_sharding(card, total_rows, max_parents, world)
         if sharding not in ("subsets", "rows"):
             raise ValueError("sharding must be 'subsets', 'rows' or 'auto'")
-        if world == 1:
-            sharding = "subsets"
-        self.sharding = sharding
+        self.sharding = sharding      # (an explicit 'rows' holds in a world of one too: the same calls on all rows)
         if sharding == "rows":
             lo, hi = row_slice(total_rows, rank, world)
             if hi <= lo:

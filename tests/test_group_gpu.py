@@ -72,7 +72,7 @@ def test_group_that_splits_the_rows_equals_single_device(world):
     for a, b in zip(g.score_tables(mp), tabs):
         assert np.array_equal(a, b)
     assert g.exhaustive_search(mp) == search
-    # a size the engine counts per row cannot be summed over row slices: the subsets are split instead
+    # a pass over fewer sizes lays the count tables out anew (another contiguous range)
     got2 = g.best_parents(1, repack=True)
     one = engine.Data(codes, card)
     dev2 = [torch.from_numpy(one.score_all(k).reshape(-1)).cuda() for k in (1, 2)]

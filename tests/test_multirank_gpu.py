@@ -62,10 +62,12 @@ def test_two_ranks_one_gpu(sharding):
         assert min(res[0][2][k - 1], res[1][2][k - 1]) >= 0
 
 
-def test_bench_exchange_path_over_rccl_with_one_rank():
-    """bench.py with the process group, the all-gather (backend nccl = RCCL) and
-    the combine kernel switched on in a world of one rank: the code path the
-    multi-GPU runs take, as far as one GPU can exercise it."""
+@pytest.mark.parametrize("sharding", ["subsets", "rows"])
+def test_bench_exchange_path_over_rccl_with_one_rank(sharding):
+    """bench.py with the process group, the all-reduce of the count tables in place in the
+    engine's memory, the all-gather (backend nccl = RCCL) and the combine kernel switched on
+    in a world of one rank: the code path the multi-GPU runs take, as far as one GPU can
+    exercise it, for both ways of splitting a pass."""
     import json
     import os
     import subprocess
@@ -73,12 +75,13 @@ def test_bench_exchange_path_over_rccl_with_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OBNSL_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "asia8_1e5_bdeu_mp2",
-                          "--steps", "3", "--warmup", "1", "--only-hot-path"],
+                          "--steps", "3", "--warmup", "1", "--only-hot-path", "--sharding", sharding],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["scores_per_step"] == 232
+    assert rec["config"]["sharding"].startswith(sharding)
 
 
 def test_large_tile_instances_still_count_exactly():
