@@ -179,6 +179,8 @@ struct obnsl_data {
   bool beside_large = false;                          // the launches of obnsl_precount run beside one of many tiles
   std::vector<obnsl_internal::Plan*> lane_plans[2];   // plans whose counts a lane is still producing
   std::vector<std::unique_ptr<obnsl_internal::TogetherLaunch>> together;  // launches over several subset sizes
+  // by subset size k: the variables of every size-k subset, [rank * k + j] (built on first use)
+  std::map<uint32_t, std::unique_ptr<obnsl_internal::DevBuf<uint16_t>>> subset_vars;
   // per ess: lgamma(ess / c) for c = 1..REDUCED_MAX_CELLS (index c), from the host's libm
   std::map<double, std::unique_ptr<obnsl_internal::DevBuf<double>>> lg_alpha;
   hipStream_t count_stream() const {
@@ -240,6 +242,9 @@ obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, u
 obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_scores, uint32_t max_parents,
                                 unsigned long long* keys, bool skip_first_pass, double* decode_out = nullptr);
 uint64_t whole_below(const Plan* p);
+// The table of obnsl_data::subset_vars for size k, or null where it would be too large
+// (or is not built yet and may_build is false: callers that must not allocate).
+obnsl_status subset_vars_table(obnsl_data* d, uint32_t k, bool may_build, const uint16_t** out);
 obnsl_status score_all_impl(obnsl_data* d, obnsl_score_kind kind, double ess, uint32_t k, uint32_t shard,
                             uint32_t num_shards, double* scores_out, int out_on_device);
 
@@ -304,6 +309,7 @@ void launch_best_init(hipStream_t s, unsigned long long* keys, unsigned long lon
 void launch_best_parents(hipStream_t s, const BestArgs& args, uint32_t n, const uint64_t* binom,
                          unsigned long long* key, unsigned long long* id, int pass, double* decode_out = nullptr,
                          unsigned int* done_counter = nullptr);
+void launch_subset_vars(hipStream_t s, const uint64_t* binom, uint32_t n, uint32_t k, uint64_t nsub, uint16_t* out);
 void launch_best_decode(hipStream_t s, const unsigned long long* keys, const unsigned long long* ids, uint32_t n,
                         double* out);
 void launch_best_combine(hipStream_t s, const double* parts, uint32_t world, uint32_t n, double* out);

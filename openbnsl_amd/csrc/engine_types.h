@@ -155,6 +155,10 @@ struct ReducedViews {
   SizeView v[KFAST + 1];
 };
 
+// The variables of every size-k subset by colex rank (what a thread otherwise finds with k
+// binary searches of dependent loads) are kept as a table while it stays within this.
+constexpr uint64_t SUBSET_VARS_MAX_BYTES = 64ull << 20;
+
 // The fused scoring launches (every subset size at once) serve sizes up to this one.
 constexpr int FUSED_KMAX = 5;
 // Words of a table's record (see the scorer): rank, cardinalities, one start per pattern.
@@ -186,6 +190,7 @@ struct ScoresAllArgs {            // scores_best_kernel
   const double* G[FUSED_KMAX + 1];   // G[k]: functional of size k by colex rank; G[0]: unused (g0)
   double* scores[FUSED_KMAX + 1];    // scores[k]: table of subset size k
   const uint8_t* mask[FUSED_KMAX + 1];  // mask[k][rank] != 0: this shard scores the table (null: all)
+  const uint16_t* vars[FUSED_KMAX + 1]; // vars[k][rank * k + j]: the subset's variables (null: unranked per thread)
   uint64_t nsubsets[FUSED_KMAX + 1];
   uint32_t block_start[FUSED_KMAX + 2];
   uint32_t kmax;
@@ -199,6 +204,7 @@ struct ScoresAllArgs {            // scores_best_kernel
 
 struct BestArgs {                 // every subset size in one launch
   const double* scores[KMAX];     // scores[k-1]: table of subset size k
+  const uint16_t* vars[KMAX];     // vars[k-1][rank * k + j]: the subset's variables (null: unranked per thread)
   uint64_t nsubsets[KMAX];
   uint32_t block_start[KMAX + 1]; // workgroups [block_start[k-1], block_start[k]) serve size k
   uint32_t kmax;

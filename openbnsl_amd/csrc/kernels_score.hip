@@ -584,6 +584,7 @@ __global__ __launch_bounds__(256) void scores_best_kernel(ScoresAllArgs a) {
   const double* __restrict__ Gk = nullptr;
   const double* __restrict__ Gp = nullptr;
   const uint8_t* __restrict__ mask = nullptr;
+  const uint16_t* __restrict__ vtab = nullptr;
   double* __restrict__ scores = nullptr;
   uint64_t nsub = 0;
   uint32_t first_block = 0, nblocks = 1;
@@ -594,6 +595,7 @@ __global__ __launch_bounds__(256) void scores_best_kernel(ScoresAllArgs a) {
       Gp = a.G[j - 1];
       scores = a.scores[j];
       mask = a.mask[j];
+      vtab = a.vars[j];
       nsub = a.nsubsets[j];
       first_block = a.block_start[j];
       nblocks = a.block_start[j + 1] - a.block_start[j];
@@ -614,9 +616,14 @@ __global__ __launch_bounds__(256) void scores_best_kernel(ScoresAllArgs a) {
     for (int j = FUSED_KMAX; j >= 1; --j) {
       vars[j - 1] = 0;
       if ((uint32_t)j > k) continue;
-      const uint32_t v = unrank_step(a.binom, a.n, (uint32_t)j, rem);
+      uint32_t v;
+      if (vtab != nullptr) {
+        v = vtab[t * k + (uint32_t)(j - 1)];
+      } else {
+        v = unrank_step(a.binom, a.n, (uint32_t)j, rem);
+        rem -= a.binom[v * (KMAX + 1) + j];
+      }
       vars[j - 1] = v;
-      rem -= a.binom[v * (KMAX + 1) + j];
       if (a.kind == OBNSL_SCORE_BIC) cells *= a.card[v];
     }
 #pragma unroll

@@ -58,12 +58,14 @@ __global__ __launch_bounds__(256) void best_parents_kernel(
   for (int j = 1; j < KMAX; ++j)
     if ((uint32_t)j < args.kmax && blockIdx.x >= args.block_start[j]) k = j + 1;
   const double* __restrict__ scores = nullptr;
+  const uint16_t* __restrict__ vtab = nullptr;
   uint64_t nsubsets = 0;
   uint32_t first_block = 0, nblocks = 1;
 #pragma unroll
   for (int j = 0; j < KMAX; ++j)
     if ((uint32_t)j + 1 == k) {
       scores = args.scores[j];
+      vtab = args.vars[j];
       nsubsets = args.nsubsets[j];
       first_block = args.block_start[j];
       nblocks = args.block_start[j + 1] - args.block_start[j];
@@ -77,11 +79,15 @@ __global__ __launch_bounds__(256) void best_parents_kernel(
   for (uint64_t t = (uint64_t)(blockIdx.x - first_block) * 256 + threadIdx.x; t < nsubsets;
        t += (uint64_t)nblocks * 256) {
     uint32_t vars[KCAP];
-    uint64_t rem = t;
-    for (uint32_t j = k; j >= 1; --j) {
-      const uint32_t v = unrank_step(binom, n, j, rem);
-      vars[j - 1] = v;
-      rem -= binom[v * (KMAX + 1) + j];
+    if (vtab != nullptr) {
+      for (uint32_t j = 0; j < k; ++j) vars[j] = vtab[t * k + j];
+    } else {
+      uint64_t rem = t;
+      for (uint32_t j = k; j >= 1; --j) {
+        const uint32_t v = unrank_step(binom, n, j, rem);
+        vars[j - 1] = v;
+        rem -= binom[v * (KMAX + 1) + j];
+      }
     }
     for (uint32_t i = 0; i < k; ++i) {
       const double sc = scores[t * k + i];
@@ -167,6 +173,19 @@ __global__ void best_combine_kernel(const double* __restrict__ parts, uint32_t w
   out[(size_t)v * 3] = bs;
   out[(size_t)v * 3 + 1] = bz;
   out[(size_t)v * 3 + 2] = br;
+}
+
+// The variables of every size-k subset, by colex rank: out[rank * k + j] (once per data set and size).
+__global__ __launch_bounds__(256) void subset_vars_kernel(const uint64_t* __restrict__ binom, uint32_t n, uint32_t k,
+                                                          uint64_t nsub, uint16_t* __restrict__ out) {
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < nsub; t += (uint64_t)gridDim.x * 256) {
+    uint64_t rem = t;
+    for (uint32_t j = k; j >= 1; --j) {
+      const uint32_t v = unrank_step(binom, n, j, rem);
+      out[t * k + j - 1] = (uint16_t)v;
+      rem -= binom[v * (KMAX + 1) + j];
+    }
+  }
 }
 
 __global__ void best_init_kernel(unsigned long long* keys, unsigned long long* ids, uint32_t n) {
@@ -340,6 +359,11 @@ void launch_best_parents(hipStream_t s, const BestArgs& args, uint32_t n, const 
   else
     hipLaunchKernelGGL(best_parents_kernel<KMAX>, dim3(grid), dim3(256), 0, s, args, n, binom, key, id, pass,
                        decode_out, done_counter);
+}
+
+void launch_subset_vars(hipStream_t s, const uint64_t* binom, uint32_t n, uint32_t k, uint64_t nsub, uint16_t* out) {
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((nsub + 255) / 256, 4096);
+  hipLaunchKernelGGL(subset_vars_kernel, dim3(std::max(grid, 1u)), dim3(256), 0, s, binom, n, k, nsub, out);
 }
 
 void launch_best_decode(hipStream_t s, const unsigned long long* keys, const unsigned long long* ids, uint32_t n,

@@ -1646,11 +1646,32 @@ static obnsl_status own_best_words(obnsl_data* d) {
   return OBNSL_OK;
 }
 
+obnsl_status subset_vars_table(obnsl_data* d, uint32_t k, bool may_build, const uint16_t** out) {
+  *out = nullptr;
+  auto it = d->subset_vars.find(k);
+  if (it != d->subset_vars.end()) {
+    *out = it->second->p;
+    return OBNSL_OK;
+  }
+  const uint64_t nsub = binom_host(d->n, k);
+  if (!may_build || nsub == 0 || nsub * k * sizeof(uint16_t) > SUBSET_VARS_MAX_BYTES) return OBNSL_OK;
+  auto buf = std::make_unique<DevBuf<uint16_t>>();
+  HIP_TRY(buf->ensure(nsub * k));
+  launch_subset_vars(d->stream, d->d_binom.p, d->n, k, nsub, buf->p);
+  HIP_TRY(hipGetLastError());
+  *out = buf->p;
+  d->subset_vars[k] = std::move(buf);
+  return OBNSL_OK;
+}
+
 obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_scores, uint32_t max_parents,
                                 unsigned long long* keys, bool skip_first_pass, double* decode_out) {
   if (max_parents + 1 > (uint32_t)KMAX || max_parents + 1 > d->n)
     return fail(OBNSL_ERR_INVALID_ARGUMENT, "max_parents must be in [0, num_of_vars-1]");
   OB_TRY(set_device(d->device));
+  // (a caller that brings its own arg-max words is one that must not allocate: the tables
+  // of the subsets' variables are used where they exist, never built)
+  const bool may_build = keys == nullptr || keys == d->best_key.p;
   if (!keys) {
     OB_TRY(own_best_words(d));
     keys = d->best_key.p;
@@ -1666,6 +1687,7 @@ obnsl_status queue_best_parents(obnsl_data* d, const double* const* d_scores, ui
   for (uint32_t k = 1; k <= max_parents + 1; ++k) {
     const uint64_t nsub = binom_host(d->n, k);
     args.scores[k - 1] = d_scores[k - 1];
+    OB_TRY(subset_vars_table(d, k, may_build, &args.vars[k - 1]));
     args.nsubsets[k - 1] = nsub;
     args.block_start[k] = args.block_start[k - 1] + (uint32_t)std::min<uint64_t>((nsub + 255) / 256, 512);
   }
@@ -1818,6 +1840,7 @@ obnsl_status score_pass_impl(obnsl_data* d, obnsl_score_kind kind, double ess, u
     sa.scores[j] = d_tables[j - 1];
     sa.nsubsets[j] = binom_host(d->n, j);
     if (num_shards > 1) OB_TRY(shard_mask(d, own, j, &sa.mask[j]));
+    OB_TRY(subset_vars_table(d, j, true, &sa.vars[j]));
   }
   for (uint32_t j = kmax + 1; j <= (uint32_t)FUSED_KMAX; ++j) fa.size[j].block_start = grid;
   const double* lg_alpha = nullptr;
