@@ -346,6 +346,10 @@ def main():
     hot = HotPath(codes, card, mp, kind=kind, ess=1.0, rank=rank, world=world, device_index=dev_index,
                   exchange=exchange, sharding=args.sharding)
     data = hot.data
+    # the count launch is timed with HIP events on its stream inside the timed region -- in a
+    # sample of the passes: an event pair costs the stream ~10 us, 2 % of a short pass
+    timing_every = max(1, min(5, args.steps // 4))
+    data.kernel_timing(timing_every)
     rows_mode = hot.sharding == "rows"
     rows_launch = data.N      # rows one count launch of this rank contracts over (its slice when the rows are split)
     tables = hot.tables
@@ -407,7 +411,7 @@ def main():
     # with HIP events on the stream it runs on (obnsl_kernel_time).
     k_top = mp + 1
     total_ms, launches = data.kernel_time(k_top)
-    launches_per_step = max(1, launches // max(1, args.steps))
+    launches_per_step = max(1, round(launches / max(1, args.steps / timing_every)))
     kernel_ms = total_ms / max(1, launches)       # average duration of one launch
     path = data.count_path(k_top)
     # scores of this rank's shard of the top size (count the finite entries)
@@ -451,6 +455,7 @@ def main():
                     "sustained_peak": MFMA_FP4_SUSTAINED_TFLOPS,
                     "kernel": f"bitgemm_mfma_kernel (subset size {k_top}, FP4 32x32x64)",
                     "kernel_ms": kernel_ms, "launches_per_step": launches_per_step,
+                    "timed_launches": launches, "timed_every_nth_step": timing_every,
                     "algorithmic_flops_per_launch": flops,
                     "algorithmic_cells_per_launch": cells,
                     "subset_sizes_in_launch": info["sizes_counted"],

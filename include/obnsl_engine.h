@@ -385,11 +385,18 @@ uint64_t obnsl_binomial(uint32_t n, uint32_t k);
 obnsl_status obnsl_unrank(uint64_t rank, uint32_t k, uint32_t* var_ids_out);
 uint64_t obnsl_rank(const uint32_t* var_ids, uint32_t k);
 
-/* Device time spent in the counting kernel (the bit-GEMM) of subset size k by
- * the obnsl_score_all calls on this data set since the last reset, measured
- * with HIP events on the data set's stream: total milliseconds and number of
- * launches.  Waits for the last call's launches if they are still running.
- * reset != 0 clears the totals of every subset size after reading. */
+/* Timing of the counting kernels (no counterpart in the reference).  Off by
+ * default: a pair of timing events around a launch costs the stream a few
+ * microseconds, which a short pass notices (about 2 % of one over 37 variables
+ * and 10^6 rows).  obnsl_kernel_timing(d, n): n = 0 off; n >= 1: the count
+ * launches of every n-th set of row bitmaps (every n-th obnsl_data_pack) are
+ * bracketed by HIP events on the stream they run on.
+ * obnsl_kernel_time: device time spent in the counting kernel (the bit-GEMM)
+ * of subset size k in the timed launches since the last reset: total
+ * milliseconds and number of timed launches.  Waits for them if they are
+ * still running.  reset != 0 clears the totals of every subset size after
+ * reading. */
+obnsl_status obnsl_kernel_timing(obnsl_data* d, uint32_t every_n);
 obnsl_status obnsl_kernel_time(obnsl_data* d, uint32_t k, double* total_ms, uint32_t* launches,
                                int reset);
 

@@ -667,6 +667,12 @@ obnsl_status obnsl_count_launch_info(obnsl_data* d, uint32_t k, uint64_t* info_o
   return OBNSL_OK;
 }
 
+obnsl_status obnsl_kernel_timing(obnsl_data* d, uint32_t every) {
+  if (!d) return fail(OBNSL_ERR_INVALID_ARGUMENT, "data is null");
+  d->timing_every = every;
+  return OBNSL_OK;
+}
+
 obnsl_status obnsl_kernel_time(obnsl_data* d, uint32_t k, double* total_ms, uint32_t* launches,
                                int reset) {
   if (!d || !total_ms || !launches || k == 0 || k > (uint32_t)KMAX)

@@ -186,7 +186,11 @@ struct obnsl_data {
   hipStream_t count_stream() const {
     return count_lane >= 0 && !obnsl_internal::env().serial ? side[count_lane] : stream;
   }
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // around each bit-GEMM launch
+  // obnsl_kernel_timing: 0 = count launches are not timed (no event records on the stream: each
+  // costs a few microseconds of a short pass), n = those of every n-th set of row bitmaps are
+  uint32_t timing_every = 0;
+  bool timed_now() const { return timing_every != 0 && epoch % timing_every == 0; }
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // around each timed count launch
   std::vector<uint32_t> ev_size;                      // subset size of each pending pair
   uint32_t ev_used = 0;                               // pending pairs
   double acc_ms[OBNSL_MAX_SUBSET + 1] = {0};          // per subset size, since the last reset

@@ -656,6 +656,8 @@ __global__ __launch_bounds__(256) void scores_best_kernel(ScoresAllArgs a) {
   }
   if (use_lds) {
     __syncthreads();
+    // (reading the word first and skipping the atomic where it cannot raise it was measured
+    // slower: 12.2 us against 9.6 for the 37-variable pass)
     for (uint32_t v = threadIdx.x; v < a.n; v += 256) {
       const unsigned long long x = s_best[v];
       if (x) atomicMax(&a.best_key[v], x);

@@ -712,8 +712,10 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
     if (counts == plan->red.p) plan->wants_zero = (flags & GEMM_ATOMIC) != 0;
   }
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  OB_TRY(next_event_pair(d, plan->k, &ev));
-  HIP_TRY(hipEventRecord(ev->first, d->count_stream()));
+  if (d->timed_now()) {
+    OB_TRY(next_event_pair(d, plan->k, &ev));
+    HIP_TRY(hipEventRecord(ev->first, d->count_stream()));
+  }
   GemmOperands op;
   op.planes = d->planes.p;
   op.wp = d->wp;
@@ -754,7 +756,7 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
     launch_image_scatter(plan->tile, d->count_stream(), b->img.p, b->items.p, b->nitems, b->rows.p, b->nrows, table);
     HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipEventRecord(ev->second, d->count_stream()));
+  if (ev) HIP_TRY(hipEventRecord(ev->second, d->count_stream()));
   return OBNSL_OK;
 }
 
@@ -889,8 +891,10 @@ obnsl_status launch_count_together(obnsl_data* d, std::vector<CountPart>& parts)
   }
 #endif
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  OB_TRY(next_event_pair(d, parts[0].plan->k, &ev));
-  HIP_TRY(hipEventRecord(ev->first, d->count_stream()));
+  if (d->timed_now()) {
+    OB_TRY(next_event_pair(d, parts[0].plan->k, &ev));
+    HIP_TRY(hipEventRecord(ev->first, d->count_stream()));
+  }
   launch_gemm_mfma(parts[0].plan->kr, top_shape.kcn, 128, d->count_stream(), op, l, top_counts, flags, env().probe);
   HIP_TRY(hipGetLastError());
   {
@@ -925,7 +929,7 @@ obnsl_status launch_count_together(obnsl_data* d, std::vector<CountPart>& parts)
       HIP_TRY(hipGetLastError());
     }
   }
-  HIP_TRY(hipEventRecord(ev->second, d->count_stream()));
+  if (ev) HIP_TRY(hipEventRecord(ev->second, d->count_stream()));
   return OBNSL_OK;
 }
 
@@ -1136,24 +1140,15 @@ obnsl_status run_hist_range(obnsl_data* d, uint32_t k, uint64_t lo, uint64_t hi,
     rpc = (rpc + HIST_ROWS_PER_ITER - 1) / HIST_ROWS_PER_ITER * HIST_ROWS_PER_ITER;
     nchunks = (d->N + rpc - 1) / rpc;
     const size_t lds = (size_t)std::min<uint32_t>(hb->max_cells, HIST_LDS_CELLS) * sizeof(uint32_t);
-    if (d->ev_used >= 4096) {  // bound the pool: fold what has been recorded so far
-      obnsl_status st = resolve_events(d);
-      if (st != OBNSL_OK) return st;
+    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+    if (d->timed_now()) {
+      OB_TRY(next_event_pair(d, k, &ev));
+      HIP_TRY(hipEventRecord(ev->first, d->stream));
     }
-    if (d->ev_used == d->ev.size()) {
-      hipEvent_t e0, e1;
-      HIP_TRY(hipEventCreate(&e0));
-      HIP_TRY(hipEventCreate(&e1));
-      d->ev.push_back({e0, e1});
-      d->ev_size.push_back(0);
-    }
-    d->ev_size[d->ev_used] = k;
-    auto& ev = d->ev[d->ev_used++];
-    HIP_TRY(hipEventRecord(ev.first, d->stream));
     launch_count_hist(d->stream, nt * (uint32_t)nchunks, lds, d->codes.p, d->stride, d->N, d->n, d->d_card.p,
                       d->d_binom.p, k, hb->rank0, (uint32_t)nchunks, rpc, hb->off.p, d->counts.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev.second, d->stream));
+    if (ev) HIP_TRY(hipEventRecord(ev->second, d->stream));
     launch_score_tables(d->stream, d->counts.p, hb->tds.p, (uint64_t)nt, (int)kind, ess, d_scores + hb->rank0 * k);
     HIP_TRY(hipGetLastError());
   }

@@ -98,6 +98,7 @@ SIGNATURES = {
     "obnsl_count_path": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int)]),
     "obnsl_stream_read": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, _vp]),
     "obnsl_kernel_time": (ctypes.c_int, [_vp, ctypes.c_uint32, _f64p, _u32p, ctypes.c_int]),
+    "obnsl_kernel_timing": (ctypes.c_int, [_vp, ctypes.c_uint32]),
 }
 
 
@@ -431,8 +432,12 @@ class Data:
         _check(lib.obnsl_count_path(self._h, k, ctypes.byref(path)))
         return {0: "mfma", 1: "valu", 2: "histogram"}[path.value]
 
+    def kernel_timing(self, every):
+        """Time the count launches of every `every`-th set of row bitmaps (0: none, the default)."""
+        _check(lib.obnsl_kernel_timing(self._h, every))
+
     def kernel_time(self, k, reset=False):
-        """(total ms, launches) of the size-k counting kernel since the last reset."""
+        """(total ms, timed launches) of the size-k counting kernel since the last reset."""
         ms = ctypes.c_double(0.0)
         n = ctypes.c_uint32(0)
         _check(lib.obnsl_kernel_time(self._h, k, ctypes.byref(ms), ctypes.byref(n), int(reset)))

@@ -275,6 +275,10 @@ def test_hot_path_device_result_matches_host_result(engine):
     from helpers import best_parents_reference
     codes, card, _, _ = synth.random_bn([2, 3, 4, 2, 3, 4, 3, 2, 4, 3], 12_000, seed=31)
     hot = HotPath(codes, card, 3)
+    assert hot.data.kernel_time(4) == (0.0, 0)       # count launches are not timed unless asked for
+    hot.step()
+    assert hot.data.kernel_time(4) == (0.0, 0)
+    hot.data.kernel_timing(1)
     for _ in range(3):
         dev = hot.step()
     sc, sz, rk = hot.to_host(dev)

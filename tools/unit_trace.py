@@ -33,6 +33,7 @@ def main():
     for _ in range(3):
         hot.step()
     torch.cuda.synchronize()
+    hot.data.kernel_timing(1)
     hot.data.kernel_time(k, reset=True)
     assert lib.obnsl_probe_trace_begin(hot.data._h, k) == 0
     for _ in range(5):
