@@ -61,6 +61,7 @@ struct Batch {
   DevBuf<uint2> items;
   std::vector<uint2> h_items;          // host copy of `items` (tile coordinates), largest first
   std::vector<uint32_t> h_item_blocks; // 32-column blocks of each item that hold a valid column
+  std::vector<uint32_t> h_item_top;    // ... and that the item's first 64 rows reach (MfmaUnit::top_blocks)
   DevBuf<MfmaUnit> units;              // matrix-core launch: work units for `units_steps` steps
   DevBuf<uint32_t> unit_start;         // `runs`: workgroup w runs units [unit_start[w], unit_start[w + 1])
   uint32_t nunits = 0, units_steps = 0, units_target = 0;

@@ -79,7 +79,7 @@ struct MfmaUnit {
   uint32_t blocks;   // 32-column blocks of the tile that hold a valid column (>= 1)
   uint32_t tile;     // index of the tile in its part's tile list (its image)
   uint32_t part;     // part of the launch (0 unless one launch counts several subset sizes)
-  uint32_t pad_;
+  uint32_t top_blocks;  // 32-column blocks that the tile's first 64 rows reach (<= blocks; 0: none of them)
 };
 
 // Operands of one contraction launch.

@@ -253,6 +253,10 @@ __device__ __forceinline__ void tile_mfma_pipelined(const uint32_t* __restrict__
 // more instructions (5 / 7.5 vector instructions per matrix instruction for two / one
 // column blocks, against 7.5 / 10 with one row block per wave).  The waves' partial
 // counts meet in the atomics of the epilogue.
+// KS = 3 (a full-width tile on the staircase whose first 64 rows reach none of its columns):
+// all four waves work on the other 64 rows -- two side by side over the four column
+// blocks, two over the halves of every slab -- instead of two waves idling through the
+// tile: about half the time.
 template <int KR, int KC, int NA, int NB, int TB, int KS = 1>
 __device__ __forceinline__ void mfma_tile_body(
     uint32_t* __restrict__ smem, const uint32_t* __restrict__ planes, uint32_t wp,
@@ -293,13 +297,13 @@ __device__ __forceinline__ void mfma_tile_body(
   // tile).  Lane (lr, h) holds row / column lr of each block, samples 128 h ..
   // 128 h + 127 of each 256-sample round.
   static_assert(KS != 1 || NA == 1 || 2 * 32 * NB == TB, "two waves side by side cover the tile's columns");
-  static_assert(KS == 1 || (TB == 128 && KS == 2 && NA == 2 && NB <= 2),
-                "the shared form: 2 x NB blocks per wave, a half of every slab");
+  static_assert(KS == 1 || (TB == 128 && KS == 2 && NA == 2 && NB <= 2) || (TB == 128 && KS == 3 && NA == 2 && NB == 2),
+                "the shared forms: 2 x NB blocks per wave, a half of every slab");
   const uint32_t lane = tid & 63, wv = tid >> 6;
   const uint32_t lr = lane & 31, h4 = (lane >> 5) * 4;
   // first row / column of the wave's blocks
-  const uint32_t wrow = KS == 2 ? (wv & 1) * 64 : NA == 1 ? wv * 32 : (wv >> 1) * 64;
-  const uint32_t wcol = KS != 1 ? 0 : NA == 1 ? 0 : (wv & 1) * (32 * NB);
+  const uint32_t wrow = KS == 3 ? 64 : KS == 2 ? (wv & 1) * 64 : NA == 1 ? wv * 32 : (wv >> 1) * 64;
+  const uint32_t wcol = KS == 3 ? (wv & 1) * (32 * NB) : KS == 2 ? 0 : NA == 1 ? 0 : (wv & 1) * (32 * NB);
   obnsl_v16f acc[NA][NB];
 #pragma unroll
   for (int a = 0; a < NA; ++a)
@@ -358,8 +362,8 @@ __device__ __forceinline__ void mfma_tile_body(
       if (more && !OBNSL_PROBE(PROBE_NOISSUE)) issue_loads(step + 1);
       const uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
       const uint32_t* sB = sA + TB * LDS_STRIDE;
-      if constexpr (KS == 2 && NB == 2) tile_mfma_pipelined<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {}, (int)(wv >> 1), (int)(wv >> 1) + 1);
-      else if constexpr (KS == 2) tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {}, (int)(wv >> 1), (int)(wv >> 1) + 1);
+      if constexpr (KS >= 2 && NB == 2) tile_mfma_pipelined<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {}, (int)(wv >> 1), (int)(wv >> 1) + 1);
+      else if constexpr (KS >= 2) tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {}, (int)(wv >> 1), (int)(wv >> 1) + 1);
       else if constexpr (NA == 2 && NB == 2) tile_mfma_pipelined<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
       else tile_mfma<NA, NB>(sA, sB, wrow + lr, wcol + lr, h4, acc, [](int) {});
       if (more && !OBNSL_PROBE(PROBE_NOWRITE)) write_slab(buf ^ 1);
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void b
       default:                                                                                    \
         if constexpr (TB == 128) {                                                                \
           if (flags & GEMM_NO_2X2) OBNSL_MFMA_BODY(1, 4);                                         \
+          else if (RUNS && u.top_blocks == 0) OBNSL_MFMA_BODY_SHARED(2, 2, 3);                    \
           else OBNSL_MFMA_BODY(2, 2);                                                             \
         } else {                                                                                  \
           if (jm == 4) OBNSL_MFMA_BODY(1, 4);                                                     \

@@ -316,6 +316,15 @@ obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nsha
     b->h_items = items;
     b->h_item_blocks.resize(tiles.size());
     for (size_t i = 0; i < tiles.size(); ++i) b->h_item_blocks[i] = (tiles[i].first + 31) / 32;
+    // the column blocks the first 64 rows of each tile reach (the rows are sorted by their
+    // number of valid columns: the 64th row has the most of them)
+    b->h_item_top.assign(tiles.size(), 0);
+    for (size_t i = 0; i < tiles.size(); ++i) {
+      const uint64_t first = (uint64_t)items[i].x * plan->tile, c0 = (uint64_t)items[i].y * plan->tile;
+      const uint64_t last = std::min<uint64_t>(first + 64, rows.size()) - 1;
+      const uint64_t lim = rows[last].ncols;
+      b->h_item_top[i] = lim <= c0 ? 0u : (uint32_t)std::min<uint64_t>((lim - c0 + 31) / 32, b->h_item_blocks[i]);
+    }
     b->nrows = (uint32_t)rows.size();
     b->nitems = (uint32_t)items.size();
     b->nrgs = (uint32_t)rgs.size();
@@ -370,10 +379,16 @@ obnsl_status resolve_events(obnsl_data* d) {
 // a valid column: a tile with fewer blocks amortises its A operand over fewer
 // instructions (measured 31 / 24 / 20 ns per instruction for 1 / 2 / 4 blocks).
 static uint32_t unit_weight(uint32_t blk) { return 2 * blk + 1; }
+// (a full-width 128 x 128 tile whose first 64 rows reach none of its columns is contracted
+// by all four waves on its other 64 rows, in about half the time: runs of units only)
+static uint32_t tile_weight(uint32_t blk, uint32_t top_blocks, uint32_t tile_edge) {
+  if (tile_edge != 128 || top_blocks != 0) return unit_weight(blk);
+  return blk == 4 ? 5 : unit_weight(blk);
+}
 
 // One tile of a launch's work: which part (subset size) it belongs to and where it is.
 struct TileRef {
-  uint32_t part, tile, row_tile, col_tile, blocks;
+  uint32_t part, tile, row_tile, col_tile, blocks, top_blocks;
 };
 struct PartShape {   // what check_units needs to know of a part
   const Batch* b;
@@ -382,7 +397,7 @@ struct PartShape {   // what check_units needs to know of a part
 
 static void tiles_of(const Batch* b, uint32_t part, std::vector<TileRef>& out) {
   for (size_t i = 0; i < b->h_items.size(); ++i)
-    out.push_back({part, (uint32_t)i, b->h_items[i].x, b->h_items[i].y, b->h_item_blocks[i]});
+    out.push_back({part, (uint32_t)i, b->h_items[i].x, b->h_items[i].y, b->h_item_blocks[i], b->h_item_top[i]});
 }
 
 // Host-side check of a unit list before it is uploaded: every unit inside its part's
@@ -405,6 +420,8 @@ static obnsl_status check_units(const std::vector<PartShape>& parts, const std::
       return fail(OBNSL_ERR_RUNTIME, "internal: work unit outside the rows or columns of the launch");
     if (u.blocks < 1 || u.blocks > tb / 32 || u.blocks != b->h_item_blocks[u.tile])
       return fail(OBNSL_ERR_RUNTIME, "internal: work unit with a bad column-block count");
+    if (u.top_blocks > u.blocks || u.top_blocks != b->h_item_top[u.tile])
+      return fail(OBNSL_ERR_RUNTIME, "internal: work unit with a bad column-block count of its first rows");
     if (u.step_lo >= u.step_hi || u.step_hi > steps_total || u.step_hi - u.step_lo > MFMA_MAX_STEPS)
       return fail(OBNSL_ERR_RUNTIME, "internal: work unit with a bad step range");
     per[u.part][u.tile].push_back({u.step_lo, u.step_hi});
@@ -469,6 +486,7 @@ static obnsl_status build_units(Batch* b, const Plan* plan, uint32_t steps_total
       u.step_hi = (uint32_t)((uint64_t)steps_total * (sidx + 1) / ns);
       u.blocks = blk;
       u.tile = (uint32_t)i;
+      u.top_blocks = b->h_item_top[i];
       tmp.push_back({unit_weight(blk) * (u.step_hi - u.step_lo), u});
     }
   }
@@ -502,7 +520,8 @@ static void cut_runs(const std::vector<TileRef>& tiles, uint32_t steps_total, ui
   unit_start.clear();
   const size_t nt = tiles.size();
   std::vector<uint64_t> start(nt + 1, 0);   // position of each tile on the line
-  for (size_t i = 0; i < nt; ++i) start[i + 1] = start[i] + (uint64_t)unit_weight(tiles[i].blocks) * steps_total;
+  for (size_t i = 0; i < nt; ++i)
+    start[i + 1] = start[i] + (uint64_t)tile_weight(tiles[i].blocks, tiles[i].top_blocks, 128) * steps_total;
   const double total = (double)start[nt];
   // a point of the line as (tile, step), rounded to whole steps
   auto locate = [&](double x, size_t& tile, uint32_t& step) {
@@ -513,7 +532,7 @@ static void cut_runs(const std::vector<TileRef>& tiles, uint32_t steps_total, ui
     }
     size_t i = std::upper_bound(start.begin(), start.end(), (uint64_t)x) - start.begin() - 1;
     i = std::min(i, nt - 1);
-    const double w = (double)unit_weight(tiles[i].blocks);
+    const double w = (double)tile_weight(tiles[i].blocks, tiles[i].top_blocks, 128);
     uint32_t st = (uint32_t)std::min<double>(steps_total, std::floor((x - (double)start[i]) / w + 0.5));
     if (st >= steps_total) {
       ++i;
@@ -549,6 +568,7 @@ static void cut_runs(const std::vector<TileRef>& tiles, uint32_t steps_total, ui
         u.step_lo = cur_step;
         u.step_hi = end;
         u.blocks = tiles[cur_tile].blocks;
+        u.top_blocks = tiles[cur_tile].top_blocks;
         u.tile = tiles[cur_tile].tile;
         u.part = tiles[cur_tile].part;
         units.push_back(u);
@@ -744,7 +764,12 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
     info[1] = b->nunits;
     info[2] = b->nworkgroups;
     info[3] = 0;
-    for (uint32_t blk : b->h_item_blocks) info[3] += (uint64_t)plan->tile * 32 * blk;
+    for (size_t i = 0; i < b->h_item_blocks.size(); ++i) {
+      const uint32_t blk = b->h_item_blocks[i];
+      // (runs of units contract only the lower 64 rows of a full-width tile whose upper rows reach no column)
+      const bool lower_only = b->runs && plan->tile == 128 && blk == 4 && b->h_item_top[i] == 0;
+      info[3] += (uint64_t)(lower_only ? 64 : plan->tile) * 32 * blk;
+    }
     info[4] = b->ncells;
     info[5] = 1;
   } else {
@@ -905,7 +930,11 @@ obnsl_status launch_count_together(obnsl_data* d, std::vector<CountPart>& parts)
     info[5] = parts.size();
     for (const CountPart& cp : parts) {
       info[0] += cp.b->nitems;
-      for (uint32_t blk : cp.b->h_item_blocks) info[3] += (uint64_t)cp.plan->tile * 32 * blk;
+      for (size_t i = 0; i < cp.b->h_item_blocks.size(); ++i) {
+        const uint32_t blk = cp.b->h_item_blocks[i];
+        const bool lower_only = cp.plan->tile == 128 && blk == 4 && cp.b->h_item_top[i] == 0;
+        info[3] += (uint64_t)(lower_only ? 64 : cp.plan->tile) * 32 * blk;
+      }
       info[4] += cp.b->ncells;
     }
   }
