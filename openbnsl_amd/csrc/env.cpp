@@ -23,8 +23,8 @@
 //   OBNSL_RUN_PHASES=a,b,..  shares (percent) of such a launch per phase of runs (default 80,12,8)
 //   OBNSL_RUN_PIECES=a,b,..  runs per workgroup slot in each phase (default 1,1,1)
 //   OBNSL_NO_TOGETHER        one count launch per subset size, never one persistent launch for all sizes
-//   OBNSL_TOGETHER_PHASES=.. / OBNSL_TOGETHER_PIECES=..  phases of that launch (default 72,14,14 / 1,1,2;
-//                            70,30 and 100 for launches of fewer than 110 / 28 steps per workgroup slot)
+//   OBNSL_TOGETHER_PHASES=.. / OBNSL_TOGETHER_PIECES=..  phases of that launch (default 74,26 / 1,2;
+//                            70,30 / 1,1 and 100 for launches of fewer than 56 / 28 steps per workgroup slot)
 //   OBNSL_RUNS_MAX_STEPS=n   longest launch, in contraction steps per workgroup slot, that takes the form
 //   OBNSL_PROBE=<bits>       timing probes; honoured only by a library built with -DOBNSL_PROBES
 //
@@ -136,8 +136,8 @@ Env read_env() {
     if (!pc.empty()) x.run_pieces = pc;
   }
   x.together = !flag("OBNSL_NO_TOGETHER");
-  x.together_phases = {0.72, 0.14, 0.14};
-  x.together_pieces = {1, 1, 2};
+  x.together_phases = {0.74, 0.26};
+  x.together_pieces = {1, 2};
   {
     const std::vector<double> ph = shares("OBNSL_TOGETHER_PHASES");
     if (!ph.empty()) {

@@ -835,9 +835,12 @@ obnsl_status launch_count_together(obnsl_data* d, std::vector<CountPart>& parts)
     // one more prologue and flush each: worth it for long runs only.  Measured on the
     // 37-variable pass over 1/1, 1/2, 1/4 and 1/8 of 10^6 rows (147, 74, 37 and 19 steps per
     // slot), launch in ms: phases (65, 15, 10, 10) 0.412 0.242 0.169 0.142, (70, 30) - 0.235 0.133
-    // 0.089, one phase - 0.276 0.145 0.087.  For the long launch, (72, 14, 14) with the last
-    // phase in runs of half the length: 0.400 (any first share from 66 to 74 with two equal
-    // later ones: 0.400-0.403; a last phase cut in three, or four phases: 0.416-0.429).
+    // 0.089, one phase - 0.276 0.145 0.087.  The default, (74, 26) with the second phase in
+    // runs of half its slot share: 0.396 and 0.220 for the first two (first shares from 73
+    // to 75: 0.395-0.398; 76 and more: 0.409-0.428; (72, 14, 14) with the last phase in
+    // half-length runs 0.400; three runs per slot in the last phase, or four phases:
+    // 0.416-0.429): every run costs its workgroup ~7 us of prologue and flush, every run
+    // too long a tail.
     std::vector<double> phases = env().together_phases;
     std::vector<uint32_t> pieces = env().together_pieces;
     if (!env().together_phases_set) {
@@ -847,7 +850,7 @@ obnsl_status launch_count_together(obnsl_data* d, std::vector<CountPart>& parts)
       if (per_slot < 28) {
         phases = {1.0};
         pieces = {1};
-      } else if (per_slot < 110) {
+      } else if (per_slot < 56) {
         phases = {0.7, 0.3};
         pieces = {1, 1};
       }
