@@ -110,3 +110,35 @@ def test_row_slices_refuse_what_they_cannot_serve():
     d.score_pass([t.data_ptr() for t in tabs], 1)                    # (scores of half the counts: not checked)
     torch.cuda.synchronize()
     d.close()
+
+
+def test_drivers_fall_back_to_splitting_the_subsets():
+    """Where a size is counted per row, neither driver splits the rows, whatever it was asked:
+    the pipeline object reports 'subsets', the group's results equal the single device's."""
+    import os
+    import torch
+    from openbnsl_amd import engine, synth
+    from openbnsl_amd.pipeline import HotPath
+    codes, card, _ = synth.uniform(9, 8, 40_000, seed=6)     # size-4 tables of 4096 cells: counted per row
+    mp = 3
+    hot = HotPath(codes, card, mp, rank=1, world=2, exchange=False, sharding="rows")
+    assert hot.sharding == "subsets" and hot.data.N == 40_000
+    hot.close()
+    one = engine.Data(codes, card)
+    tabs = [one.score_all(k) for k in range(1, mp + 2)]
+    dev = [torch.from_numpy(t.reshape(-1)).cuda() for t in tabs]
+    want = one.best_parents([t.data_ptr() for t in dev], mp)
+    one.close()
+    os.environ["OBNSL_GROUP_SHARDING"] = "rows"
+    try:
+        g = engine.Group(codes, card, [0, 0, 0])
+    finally:
+        del os.environ["OBNSL_GROUP_SHARDING"]
+    got = g.best_parents(mp, repack=True)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    got2 = g.best_parents(1, repack=True)                      # sizes 1 and 2 alone can split the rows
+    dev2 = [torch.from_numpy(t.reshape(-1)).cuda() for t in tabs[:2]]
+    one = engine.Data(codes, card)
+    assert all(np.array_equal(a, b) for a, b in zip(got2, one.best_parents([t.data_ptr() for t in dev2], 1)))
+    one.close()
+    g.close()
