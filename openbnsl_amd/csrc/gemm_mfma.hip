@@ -257,7 +257,12 @@ __device__ __forceinline__ void tile_mfma_pipelined(const uint32_t* __restrict__
 // all four waves work on the other 64 rows -- two side by side over the four column
 // blocks, two over the halves of every slab -- instead of two waves idling through the
 // tile: about half the time.
-template <int KR, int KC, int NA, int NB, int TB, int KS = 1>
+// NARROW (the persistent kernels, whose launches are short: the host sends a data set there
+// only if its bitmaps stay within 4 GB): the staging loads are buffer loads -- a scalar
+// resource for the bitmaps, a 32-bit byte offset per thread and plane that does not change
+// with the step, and the step's offset as a scalar -- instead of loads from 64-bit
+// addresses: 16 registers and one vector instruction per load and step less.
+template <int KR, int KC, int NA, int NB, int TB, int KS = 1, bool NARROW = false>
 __device__ __forceinline__ void mfma_tile_body(
     uint32_t* __restrict__ smem, const uint32_t* __restrict__ planes, uint32_t wp,
     const RowDesc* __restrict__ rows, uint32_t nrows, const ColDesc* __restrict__ cols,
@@ -323,18 +328,35 @@ __device__ __forceinline__ void mfma_tile_body(
       const uint32_t r = min(row0 + rl + PR * p, nrows - 1);
       const uint32_t c = min(col0 + rl + PR * p, ncols_total - 1);
 #pragma unroll
-      for (int j = 0; j < KR; ++j) aoff[p][j] = rows[r].plane[j] * wp + q * 4;
+      for (int j = 0; j < KR; ++j) aoff[p][j] = (rows[r].plane[j] * wp + q * 4) * (NARROW ? 4u : 1u);
 #pragma unroll
-      for (int j = 0; j < KC; ++j) boff[p][j] = cols[c].plane[j] * wp + q * 4;
+      for (int j = 0; j < KC; ++j) boff[p][j] = (cols[c].plane[j] * wp + q * 4) * (NARROW ? 4u : 1u);
     }
+    // (dword 3 of the resource: 32-bit data, no swizzle, no range check short of 4 GB)
+    const __amdgpu_buffer_rsrc_t plane_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(planes), 0, 0xffffffff, 0x00020000);
     auto issue_loads = [&](uint32_t step) {
       const uint32_t w0 = (OBNSL_PROBE(PROBE_SAMELOAD) ? step_lo : step) * KCW;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
+        if constexpr (NARROW) {
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int j = 0; j < KR; ++j) ga[p][j] = *reinterpret_cast<const uint4*>(planes + aoff[p][j] + w0);
+          for (int j = 0; j < KR; ++j) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc, (int)aoff[p][j], (int)(w0 * 4u), 0);
+            ga[p][j] = make_uint4(v.x, v.y, v.z, v.w);
+          }
 #pragma unroll
-        for (int j = 0; j < KC; ++j) gb[p][j] = *reinterpret_cast<const uint4*>(planes + boff[p][j] + w0);
+          for (int j = 0; j < KC; ++j) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc, (int)boff[p][j], (int)(w0 * 4u), 0);
+            gb[p][j] = make_uint4(v.x, v.y, v.z, v.w);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < KR; ++j) ga[p][j] = *reinterpret_cast<const uint4*>(planes + aoff[p][j] + w0);
+#pragma unroll
+          for (int j = 0; j < KC; ++j) gb[p][j] = *reinterpret_cast<const uint4*>(planes + boff[p][j] + w0);
+        }
       }
     };
     auto write_slab = [&](uint32_t buf) {
@@ -516,10 +538,10 @@ __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void b
 #endif
   constexpr uint32_t JFULL = TB / 32;
 #define OBNSL_MFMA_BODY(NA, NB)                                                                          \
-  mfma_tile_body<KR, KC, NA, NB, TB>(smem, planes, wp, p_rows, p_nrows, p_cols, p_ncols, row0, col0,      \
+  mfma_tile_body<KR, KC, NA, NB, TB, 1, RUNS>(smem, planes, wp, p_rows, p_nrows, p_cols, p_ncols, row0, col0, \
                                      p_counts, u.step_lo, u.step_hi, atomics, image, probe)
 #define OBNSL_MFMA_BODY_SHARED(NA, NB, KS)                                                               \
-  mfma_tile_body<KR, KC, NA, NB, TB, KS>(smem, planes, wp, p_rows, p_nrows, p_cols, p_ncols, row0, col0,  \
+  mfma_tile_body<KR, KC, NA, NB, TB, KS, RUNS>(smem, planes, wp, p_rows, p_nrows, p_cols, p_ncols, row0, col0, \
                                          p_counts, u.step_lo, u.step_hi, atomics, image, probe)
 #define OBNSL_MFMA_UNIT(UI)                                                                       \
   {                                                                                               \

@@ -661,7 +661,9 @@ static LaunchShape launch_shape(const obnsl_data* d, const Plan* plan, const Bat
   // unit, is what the form saves; longer launches are as fast with one unit per
   // workgroup.  (Not the 3 + 2 variable form, whose instance with the loop spills.)
   const uint64_t tile_steps = (uint64_t)b->nitems * steps_total;
-  sh.runs = env().runs && plan->mfma && plan->tile == 128 && sh.image_ok && b->nitems > 32 && b->nitems < sh.want &&
+  // (the persistent kernels address the bitmaps with 32-bit byte offsets)
+  const bool narrow = ((uint64_t)d->total_planes + 1) * d->wp * sizeof(uint32_t) <= 0xffffffffull;
+  sh.runs = env().runs && narrow && plan->mfma && plan->tile == 128 && sh.image_ok && b->nitems > 32 && b->nitems < sh.want &&
             plan->kr + sh.kcn != 5 && tile_steps >= 8ull * sh.slots &&
             tile_steps <= (uint64_t)env().runs_max_steps * sh.slots;
   return sh;
