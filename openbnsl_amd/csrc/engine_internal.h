@@ -42,6 +42,7 @@ struct Env {
   bool together = true;           // OBNSL_NO_TOGETHER clears it: one count launch per subset size, never one for all
   std::vector<double> together_phases;    // OBNSL_TOGETHER_PHASES / _PIECES: phases of the launch over all sizes
   std::vector<uint32_t> together_pieces;
+  bool wide_loads = false;                // OBNSL_WIDE_LOADS: 64-bit addresses for the bitmaps whatever their size
   bool together_phases_set = false;       // (given in the environment: not adapted to the launch's length)
   uint32_t runs_max_steps = 1024; // OBNSL_RUNS_MAX_STEPS: longest launch (contraction steps per slot) that takes the form
   int probe = 0;                  // OBNSL_PROBE=<bits>: timing probes; read only by builds with -DOBNSL_PROBES

@@ -143,6 +143,7 @@ enum GemmFlags : int {
   GEMM_ALL_BLOCKS = 2,  // compute every column block of an edge tile (OBNSL_NO_JSKIP; same results)
   GEMM_NO_2X2 = 4,      // full tiles in the 1 x 4 wave layout (OBNSL_NO_2X2; same results)
   GEMM_IMAGE = 8,       // `counts` is the launch's array of tile images
+  GEMM_NARROW = 16,     // the bitmaps stay within 4 GB: kernels that address them with 32-bit byte offsets
 };
 
 struct SizeView {            // where the reduced tables of one subset size live

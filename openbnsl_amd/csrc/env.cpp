@@ -26,6 +26,8 @@
 //   OBNSL_TOGETHER_PHASES=.. / OBNSL_TOGETHER_PIECES=..  phases of that launch (default 74,26 / 1,2;
 //                            70,30 / 1,1 and 100 for launches of fewer than 56 / 28 steps per workgroup slot)
 //   OBNSL_RUNS_MAX_STEPS=n   longest launch, in contraction steps per workgroup slot, that takes the form
+//   OBNSL_WIDE_LOADS         128 x 128 matrix-core kernels address the bitmaps with 64-bit pointers even where they
+//                            stay within 4 GB (and then never as persistent workgroups)
 //   OBNSL_PROBE=<bits>       timing probes; honoured only by a library built with -DOBNSL_PROBES
 //
 // All of them select among code paths that produce the same counts and scores.
@@ -135,6 +137,7 @@ Env read_env() {
     const std::vector<uint32_t> pc = counts_list("OBNSL_RUN_PIECES", x.run_phases.size());
     if (!pc.empty()) x.run_pieces = pc;
   }
+  x.wide_loads = flag("OBNSL_WIDE_LOADS");
   x.together = !flag("OBNSL_NO_TOGETHER");
   x.together_phases = {0.74, 0.26};
   x.together_pieces = {1, 2};

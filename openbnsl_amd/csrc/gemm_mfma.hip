@@ -282,11 +282,14 @@ __device__ __forceinline__ void mfma_tile_body(
     const uint32_t r = min(row0 + tid, nrows - 1);
     const uint32_t c = min(col0 + tid, ncols_total - 1);
 #pragma unroll
-    for (int j = 0; j < KR; ++j) sAo[tid * KR + j] = rows[r].plane[j] * wp;
+    for (int j = 0; j < KR; ++j) sAo[tid * KR + j] = rows[r].plane[j] * wp * (NARROW ? 4u : 1u);
 #pragma unroll
-    for (int j = 0; j < KC; ++j) sBo[tid * KC + j] = cols[c].plane[j] * wp;
+    for (int j = 0; j < KC; ++j) sBo[tid * KC + j] = cols[c].plane[j] * wp * (NARROW ? 4u : 1u);
   }
   const uint32_t st_off = rl * LDS_STRIDE + q * 4;
+  // (dword 3 of the resource: 32-bit data, no swizzle, no range check short of 4 GB)
+  const __amdgpu_buffer_rsrc_t plane_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(planes), 0, 0xffffffff, 0x00020000);
   // the epilogue's view of this thread's row (read now: no dependent load after the last step)
   uint64_t e_base = 0;
   uint32_t e_M = 0, e_nc = 0;   // 0 columns for a row past the end: nothing is written
@@ -332,9 +335,7 @@ __device__ __forceinline__ void mfma_tile_body(
 #pragma unroll
       for (int j = 0; j < KC; ++j) boff[p][j] = (cols[c].plane[j] * wp + q * 4) * (NARROW ? 4u : 1u);
     }
-    // (dword 3 of the resource: 32-bit data, no swizzle, no range check short of 4 GB)
-    const __amdgpu_buffer_rsrc_t plane_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(planes), 0, 0xffffffff, 0x00020000);
+
     auto issue_loads = [&](uint32_t step) {
       const uint32_t w0 = (OBNSL_PROBE(PROBE_SAMELOAD) ? step_lo : step) * KCW;
 #pragma unroll
@@ -399,12 +400,27 @@ __device__ __forceinline__ void mfma_tile_body(
     // hold 2 x 4 blocks of accumulators at two waves per SIMD).
     uint4 ga[KR], gb[KC];
     auto issue_pass = [&](uint32_t step, int p) {
-      const uint32_t w0 = (OBNSL_PROBE(PROBE_SAMELOAD) ? step_lo : step) * KCW + q * 4;
       const uint32_t r = rl + PR * p;
+      if constexpr (NARROW) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const uint32_t s0 = (OBNSL_PROBE(PROBE_SAMELOAD) ? step_lo : step) * (KCW * 4u);
 #pragma unroll
-      for (int j = 0; j < KR; ++j) ga[j] = *reinterpret_cast<const uint4*>(planes + sAo[r * KR + j] + w0);
+        for (int j = 0; j < KR; ++j) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc, (int)(sAo[r * KR + j] + q * 16u), (int)s0, 0);
+          ga[j] = make_uint4(v.x, v.y, v.z, v.w);
+        }
 #pragma unroll
-      for (int j = 0; j < KC; ++j) gb[j] = *reinterpret_cast<const uint4*>(planes + sBo[r * KC + j] + w0);
+        for (int j = 0; j < KC; ++j) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc, (int)(sBo[r * KC + j] + q * 16u), (int)s0, 0);
+          gb[j] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+      } else {
+        const uint32_t w0 = (OBNSL_PROBE(PROBE_SAMELOAD) ? step_lo : step) * KCW + q * 4;
+#pragma unroll
+        for (int j = 0; j < KR; ++j) ga[j] = *reinterpret_cast<const uint4*>(planes + sAo[r * KR + j] + w0);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) gb[j] = *reinterpret_cast<const uint4*>(planes + sBo[r * KC + j] + w0);
+      }
     };
     auto write_pass = [&](uint32_t buf, int p) {
       uint32_t* sA = smem + buf * 2 * TB * LDS_STRIDE;
@@ -515,7 +531,7 @@ __device__ __forceinline__ void mfma_tile_body(
 // one workgroup's end and its successor's start once per unit.  Every workgroup leaves
 // the loop on the first queue index past the last run.  (The loop costs registers
 // that the 256 x 256 form does not have: RUNS goes with 128 x 128 tiles only.)
-template <int KR, int KC, int TB, bool RUNS>
+template <int KR, int KC, int TB, bool RUNS, bool NARROW>
 __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void bitgemm_mfma_kernel(
     const uint32_t* __restrict__ planes, uint32_t wp, const RowDesc* __restrict__ rows,
     uint32_t nrows, const ColDesc* __restrict__ cols, uint32_t ncols_total,
@@ -538,10 +554,10 @@ __global__ __launch_bounds__(2 * TB, (TB == 128 && KR + KC <= 5) ? 2 : 1) void b
 #endif
   constexpr uint32_t JFULL = TB / 32;
 #define OBNSL_MFMA_BODY(NA, NB)                                                                          \
-  mfma_tile_body<KR, KC, NA, NB, TB, 1, RUNS>(smem, planes, wp, p_rows, p_nrows, p_cols, p_ncols, row0, col0, \
+  mfma_tile_body<KR, KC, NA, NB, TB, 1, NARROW>(smem, planes, wp, p_rows, p_nrows, p_cols, p_ncols, row0, col0, \
                                      p_counts, u.step_lo, u.step_hi, atomics, image, probe)
 #define OBNSL_MFMA_BODY_SHARED(NA, NB, KS)                                                               \
-  mfma_tile_body<KR, KC, NA, NB, TB, KS, RUNS>(smem, planes, wp, p_rows, p_nrows, p_cols, p_ncols, row0, col0, \
+  mfma_tile_body<KR, KC, NA, NB, TB, KS, NARROW>(smem, planes, wp, p_rows, p_nrows, p_cols, p_ncols, row0, col0, \
                                          p_counts, u.step_lo, u.step_hi, atomics, image, probe)
 #define OBNSL_MFMA_UNIT(UI)                                                                       \
   {                                                                                               \
@@ -683,14 +699,14 @@ __global__ __launch_bounds__(256) void image_scatter_parts_kernel(ScatterParts s
   }
 }
 
-template <int KR, int KC, int TB, bool RUNS>
+template <int KR, int KC, int TB, bool RUNS, bool NARROW>
 void launch_form(hipStream_t s, const GemmOperands& op, const MfmaLaunch& l, uint32_t* counts, int flags) {
 #ifdef OBNSL_PROBES
-  hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC, TB, RUNS>), dim3(l.nworkgroups), dim3(2 * TB), 0, s, op.planes,
+  hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC, TB, RUNS, NARROW>), dim3(l.nworkgroups), dim3(2 * TB), 0, s, op.planes,
                      op.wp, op.rows, op.nrows, op.cols, op.ncols_total, l.units, l.unit_start, l.nruns, l.queue,
                      counts, flags, l.extra, l.trace);
 #else
-  hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC, TB, RUNS>), dim3(l.nworkgroups), dim3(2 * TB), 0, s, op.planes,
+  hipLaunchKernelGGL((bitgemm_mfma_kernel<KR, KC, TB, RUNS, NARROW>), dim3(l.nworkgroups), dim3(2 * TB), 0, s, op.planes,
                      op.wp, op.rows, op.nrows, op.cols, op.ncols_total, l.units, l.unit_start, l.nruns, l.queue,
                      counts, flags, l.extra);
 #endif
@@ -698,12 +714,19 @@ void launch_form(hipStream_t s, const GemmOperands& op, const MfmaLaunch& l, uin
 template <int KR, int KC, int TB>
 void launch_one(hipStream_t s, const GemmOperands& op, const MfmaLaunch& l, uint32_t* counts, int flags) {
   if constexpr (TB == 128) {
+    // (the persistent form exists for narrow data sets only: the host checks)
     if (l.unit_start != nullptr) {
-      launch_form<KR, KC, TB, true>(s, op, l, counts, flags);
+      launch_form<KR, KC, TB, true, true>(s, op, l, counts, flags);
+      return;
+    }
+    if (flags & GEMM_NARROW) {
+      launch_form<KR, KC, TB, false, true>(s, op, l, counts, flags);
       return;
     }
   }
-  launch_form<KR, KC, TB, false>(s, op, l, counts, flags);
+  // (256 x 256 tiles keep 64-bit addresses: with buffer loads, whose offsets they read from
+  // LDS pass by pass, the 128-variable launch took 2762 ms against 2631)
+  launch_form<KR, KC, TB, false, false>(s, op, l, counts, flags);
 }
 
 }  // namespace

@@ -659,12 +659,12 @@ static LaunchShape launch_shape(const obnsl_data* d, const Plan* plan, const Bat
   // more than 32 tiles.  "Short": at most 1024 contraction steps per workgroup slot --
   // there the gap between one workgroup's end and its successor's start, ~10 us per
   // unit, is what the form saves; longer launches are as fast with one unit per
-  // workgroup.  (Not the 3 + 2 variable form, whose instance with the loop spills.)
+  // workgroup.
   const uint64_t tile_steps = (uint64_t)b->nitems * steps_total;
   // (the persistent kernels address the bitmaps with 32-bit byte offsets)
-  const bool narrow = ((uint64_t)d->total_planes + 1) * d->wp * sizeof(uint32_t) <= 0xffffffffull;
+  const bool narrow = ((uint64_t)d->total_planes + 1) * d->wp * sizeof(uint32_t) <= 0xffffffffull && !env().wide_loads;
   sh.runs = env().runs && narrow && plan->mfma && plan->tile == 128 && sh.image_ok && b->nitems > 32 && b->nitems < sh.want &&
-            plan->kr + sh.kcn != 5 && tile_steps >= 8ull * sh.slots &&
+            tile_steps >= 8ull * sh.slots &&
             tile_steps <= (uint64_t)env().runs_max_steps * sh.slots;
   return sh;
 }
@@ -721,6 +721,8 @@ obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts,
   }
   int flags = ((plan->mfma ? b->units_split : ksplit > 1) ? GEMM_ATOMIC : 0) |
               (env().no_jskip ? GEMM_ALL_BLOCKS : 0) | (env().no_2x2 ? GEMM_NO_2X2 : 0);
+  if (((uint64_t)d->total_planes + 1) * d->wp * sizeof(uint32_t) <= 0xffffffffull && !env().wide_loads)
+    flags |= GEMM_NARROW;
   const bool image = sh.image_ok && (flags & GEMM_ATOMIC);
   if (plan->mfma && b->runs && !image) return fail(OBNSL_ERR_RUNTIME, "internal: runs of units without tile images");
   uint32_t* table = counts;
