@@ -44,7 +44,7 @@ struct Env {
   std::vector<uint32_t> together_pieces;
   bool wide_loads = false;                // OBNSL_WIDE_LOADS: 64-bit addresses for the bitmaps whatever their size
   bool together_phases_set = false;       // (given in the environment: not adapted to the launch's length)
-  uint32_t runs_max_steps = 1024; // OBNSL_RUNS_MAX_STEPS: longest launch (contraction steps per slot) that takes the form
+  uint32_t runs_max_steps = 2048; // OBNSL_RUNS_MAX_STEPS: longest launch (contraction steps per slot) that takes the form
   int probe = 0;                  // OBNSL_PROBE=<bits>: timing probes; read only by builds with -DOBNSL_PROBES
 };
 const Env& env();

@@ -23,7 +23,7 @@
 //   OBNSL_RUN_PHASES=a,b,..  shares (percent) of such a launch per phase of runs (default 80,12,8)
 //   OBNSL_RUN_PIECES=a,b,..  runs per workgroup slot in each phase (default 1,1,1)
 //   OBNSL_NO_TOGETHER        one count launch per subset size, never one persistent launch for all sizes
-//   OBNSL_TOGETHER_PHASES=.. / OBNSL_TOGETHER_PIECES=..  phases of that launch (default 74,26 / 1,2;
+//   OBNSL_TOGETHER_PHASES=.. / OBNSL_TOGETHER_PIECES=..  phases of that launch (default 72,28 / 1,2;
 //                            70,30 / 1,1 and 100 for launches of fewer than 56 / 28 steps per workgroup slot)
 //   OBNSL_RUNS_MAX_STEPS=n   longest launch, in contraction steps per workgroup slot, that takes the form
 //   OBNSL_WIDE_LOADS         128 x 128 matrix-core kernels address the bitmaps with 64-bit pointers even where they
@@ -127,7 +127,7 @@ Env read_env() {
   x.runs = !flag("OBNSL_NO_RUNS");
   x.run_phases = {0.80, 0.12, 0.08};
   x.run_pieces = {1, 1, 1};
-  x.runs_max_steps = (uint32_t)number("OBNSL_RUNS_MAX_STEPS", 1024);
+  x.runs_max_steps = (uint32_t)number("OBNSL_RUNS_MAX_STEPS", 2048);
   {
     const std::vector<double> ph = shares("OBNSL_RUN_PHASES");
     if (!ph.empty()) {
@@ -139,7 +139,7 @@ Env read_env() {
   }
   x.wide_loads = flag("OBNSL_WIDE_LOADS");
   x.together = !flag("OBNSL_NO_TOGETHER");
-  x.together_phases = {0.74, 0.26};
+  x.together_phases = {0.72, 0.28};
   x.together_pieces = {1, 2};
   {
     const std::vector<double> ph = shares("OBNSL_TOGETHER_PHASES");

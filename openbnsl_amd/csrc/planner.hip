@@ -656,7 +656,7 @@ static LaunchShape launch_shape(const obnsl_data* d, const Plan* plan, const Bat
   sh.kcn = plan->kc == 0 ? 1 : plan->kc;  // kc == 0: the single ONES column
   sh.slots = d->num_cus * ((plan->kr + sh.kcn <= 5) ? 2u : 1u);
   // Runs of units: short launches of 128 x 128 tiles, cut along the contraction anyway, of
-  // more than 32 tiles.  "Short": at most 1024 contraction steps per workgroup slot --
+  // more than 32 tiles.  "Short": at most 2048 contraction steps per workgroup slot --
   // there the gap between one workgroup's end and its successor's start, ~10 us per
   // unit, is what the form saves; longer launches are as fast with one unit per
   // workgroup.
