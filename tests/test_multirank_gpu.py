@@ -99,6 +99,22 @@ def test_large_tile_instances_still_count_exactly():
     assert "smoke ok" in out.stdout
 
 
+def test_wide_addressing_still_counts_exactly():
+    """The 128 x 128 matrix-core kernels address the row bitmaps with 32-bit byte offsets
+    where those fit 4 GB (every data set of this suite); OBNSL_WIDE_LOADS=1 selects the
+    64-bit form that larger data sets take (read once per process, hence the child process).
+    The smoke check compares scores of subset sizes 1..4 and one table with the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OBNSL_WIDE_LOADS="1")
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root,
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "smoke ok" in out.stdout
+
+
 def _full_size_worker(rank, world, port, q, workload, sharding):
     """One rank of a benchmark workload at its own size (ranks share the one GPU,
     gloo on host copies): the sharded pass twice, then rank 0 runs the same pass
