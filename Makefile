@@ -21,7 +21,7 @@ all: $(ENGINE) oracle
 endif
 
 CSRC := openbnsl_amd/csrc
-ENGINE_SRC := $(CSRC)/abi.hip $(CSRC)/planner.hip $(CSRC)/gemm_mfma.hip $(CSRC)/gemm_valu.hip \
+ENGINE_SRC := $(CSRC)/abi.hip $(CSRC)/planner.hip $(CSRC)/passes.hip $(CSRC)/gemm_mfma.hip $(CSRC)/gemm_valu.hip \
               $(CSRC)/kernels_count.hip $(CSRC)/kernels_score.hip $(CSRC)/kernels_search.hip \
               $(CSRC)/group.hip $(CSRC)/env.cpp $(CSRC)/anneal.cpp $(CSRC)/score_file.cpp
 ENGINE_HDR := $(CSRC)/engine_internal.h $(CSRC)/engine_types.h $(CSRC)/engine_state.h include/obnsl_engine.h

@@ -1,5 +1,5 @@
 // abi.hip -- the C ABI of libobnsl_engine.so (include/obnsl_engine.h): argument
-// checks, the reference's error messages, and the calls into planner.hip and the
+// checks, the reference's error messages, and the calls into planner.hip, passes.hip and the
 // kernel launchers.  Each entry point's comment in the header names the reference
 // interface it replaces.
 #include <hip/hip_runtime.h>

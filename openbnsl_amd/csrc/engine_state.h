@@ -1,7 +1,8 @@
 // Host-side state of a data set (the row bitmaps, the launch plans of every subset
 // size, their count tables) and the functions the translation units of
-// libobnsl_engine.so share: planner.hip builds and runs the plans, the kernel
-// files export one launcher per kernel, abi.hip is the C ABI.  Not installed.
+// libobnsl_engine.so share: planner.hip builds the plans and queues the count launches,
+// passes.hip orders the passes, the kernel files export one launcher per kernel, abi.hip is
+// the C ABI.  Not installed.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -220,9 +221,12 @@ struct obnsl_data {
 
 namespace obnsl_internal {
 
-// ---- planner.hip: plans, launches and the data set's count tables
+// ---- planner.hip, passes.hip: plans, launches, passes and the data set's count tables
 obnsl_status build_plan(obnsl_data* d, uint32_t k, uint32_t shard, uint32_t nshards, bool reduced, Plan** out);
 obnsl_status resolve_events(obnsl_data* d);
+bool use_mfma_gemm();
+// The next pair of timing events of the data set (created on first use), booked under subset size k.
+obnsl_status next_event_pair(obnsl_data* d, uint32_t k, std::pair<hipEvent_t, hipEvent_t>** out);
 obnsl_status launch_count(obnsl_data* d, Plan* plan, Batch* b, uint32_t* counts, bool prezeroed = false);
 bool can_count_together(const obnsl_data* d, const std::vector<CountPart>& parts);
 obnsl_status launch_count_together(obnsl_data* d, std::vector<CountPart>& parts);
